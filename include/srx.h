@@ -1,0 +1,160 @@
+/*
+ * srx.h -- C ABI of the MI355X (gfx950) super-resolution path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, integer status codes,
+ * no exceptions and no framework types.  One srx_ctx owns everything a frame
+ * needs on ONE GPU: the folded, truncated and MFMA-packed weights, the
+ * activation workspace and the input / output images in HBM.  A ctx is not
+ * thread-safe; work is submitted in order on the HIP stream the caller passes
+ * (NULL = the default stream).  The host C++ classes SuperResolution /
+ * SuperResolutionX in superresolution_amd/csrc sit on top of exactly these calls.
+ *
+ * Each entry point names the reference interface it replaces; paths are
+ * relative to the reference tree (StarsX/SuperResolution).
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srx_ctx srx_ctx;
+typedef int32_t srx_status;
+
+enum {
+    SRX_OK = 0,
+    SRX_ERR_INVALID = 1,   /* bad argument                                         */
+    SRX_ERR_WEIGHTS = 2,   /* weights.bin missing / malformed (LoadWeights == false) */
+    SRX_ERR_HIP = 3,       /* a HIP runtime call failed; see srx_last_error()      */
+    SRX_ERR_NOMEM = 4,
+    SRX_ERR_STATE = 5      /* call made out of order (e.g. read of a tensor not kept) */
+};
+
+/* srx_create flags */
+enum {
+    /* Keep every layer's activations in HBM so srx_read_tensor() can return
+     * them (the debug taps used by the per-layer parity tests). */
+    SRX_FLAG_KEEP_TENSORS = 1u << 0,
+    /* Print "Number of weight tensors" / "Loaded tensor: ..." like
+     * Content/LoadWeights.cpp:50,75 while parsing weights.bin. */
+    SRX_FLAG_VERBOSE_WEIGHTS = 1u << 1
+};
+
+/* Tensor ids for srx_read_tensor(), in graph order
+ * (Content/SuperResolution.cpp:172-275). */
+enum {
+    SRX_T_INPUT = 0,    /* [3,H,W]   CSImageToTensor output (m_modelInput)        */
+    SRX_T_CONV1,        /* [32,H,W]                                               */
+    SRX_T_CONV2,        /* [64,H,W]                                               */
+    SRX_T_CONV3,        /* [64,H,W]                                               */
+    SRX_T_CONV_UP1,     /* [32,2H,2W]                                             */
+    SRX_T_CONV4,        /* [32,2H,2W]                                             */
+    SRX_T_CONV5,        /* [32,2H,2W]                                             */
+    SRX_T_CONV6,        /* [3,2H,2W] residual                                     */
+    SRX_T_OUTPUT,       /* [3,2H,2W] NN2x(input) + residual (m_modelOutput)       */
+    SRX_T_COUNT
+};
+
+/*
+ * Replaces SuperResolution::Init + createResources + initResources
+ * (Content/SuperResolution.cpp:25-55, :142-306, :452-712): parses weights.bin
+ * (Content/LoadWeights.cpp:21-93), folds batch-norm scale into the filters and
+ * truncates to fp16 exactly as ML::Util::CreateWeightTensors does
+ * (XUSG/MachineLearning/XUSGMachineLearning.h:856-858), re-lays the filters out
+ * for the MFMA kernels (the counterpart of DirectML's managed-weight
+ * initialisation, SuperResolution.cpp:615-627) and allocates the workspace for
+ * `batch` frames of in_w x in_h pixels on `device`.
+ */
+srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
+                      uint32_t in_w, uint32_t in_h, uint32_t batch, uint32_t flags);
+srx_status srx_destroy(srx_ctx* ctx);
+
+/* SuperResolution::GetOutWidth / GetOutHeight (Content/SuperResolution.cpp:132-140). */
+srx_status srx_get_out_size(const srx_ctx* ctx, uint32_t* out_w, uint32_t* out_h);
+srx_status srx_get_in_size(const srx_ctx* ctx, uint32_t* in_w, uint32_t* in_h, uint32_t* batch);
+
+/*
+ * Replace the texture upload of CreateTextureFromFile
+ * (XUSG/Advanced/XUSGTextureLoader.h:50-65): copy one decoded 8-bit frame into
+ * the ctx's RGBA8 input image in HBM.  `pitch` is the host row pitch in bytes.
+ * srx_upload_rgb8 expands 3-channel data to RGBA (alpha 255) as the loader
+ * does for 3-channel files (XUSGTextureLoader.h:20).
+ */
+srx_status srx_upload_rgba8(srx_ctx* ctx, uint32_t frame, const uint8_t* host_rgba,
+                            size_t pitch, void* stream);
+srx_status srx_upload_rgb8(srx_ctx* ctx, uint32_t frame, const uint8_t* host_rgb,
+                           size_t pitch, void* stream);
+
+/* Device-resident RGBA8 input / output images of one frame (for callers that
+ * produce or consume frames on the GPU).  Rows are *pitch bytes apart. */
+srx_status srx_input_device_ptr(srx_ctx* ctx, uint32_t frame, void** dptr, size_t* pitch);
+srx_status srx_output_device_ptr(srx_ctx* ctx, uint32_t frame, void** dptr, size_t* pitch);
+
+/* SuperResolution::ImageToTensors (Content/SuperResolution.cpp:57-71) +
+ * CSImageToTensor.hlsl:15-45: RGBA8 image -> fp16 input tensor, all frames. */
+srx_status srx_image_to_tensor(srx_ctx* ctx, void* stream);
+
+/* SuperResolution::Process (Content/SuperResolution.cpp:73-103): the two
+ * upsamples, seven convolutions and the residual add, all frames.  The last
+ * kernel's epilogue also performs the R8G8B8A8_UNORM conversion of
+ * PSTensorToImage.hlsl:14-35, so the RGBA8 output image is complete when this
+ * returns to the stream. */
+srx_status srx_process(srx_ctx* ctx, void* stream);
+
+/* SuperResolution::Render (Content/SuperResolution.cpp:105-130) with the swap
+ * chain replaced by a caller buffer: copies frame `frame` of the RGBA8 output
+ * image to host memory (rows `pitch` bytes apart).  With
+ * SRX_FLAG_KEEP_TENSORS the image is first re-derived from the fp16 output
+ * tensor by the stand-alone unpack kernel.  Asynchronous on `stream`. */
+srx_status srx_tensor_to_image(srx_ctx* ctx, uint32_t frame, uint8_t* host_rgba,
+                               size_t pitch, void* stream);
+
+/* ImageToTensors + Process in one call (what OnRender does on the first frame,
+ * SuperResolutionX.cpp:347-353). */
+srx_status srx_upscale(srx_ctx* ctx, void* stream);
+
+/* WaitForGpu (SuperResolutionX.cpp:374-385). */
+srx_status srx_sync(srx_ctx* ctx, void* stream);
+
+/* Debug tap: copy a kept tensor of one frame to host as planar CHW fp16
+ * (the reference's effective layout, Content/SuperResolution.cpp:155-159).
+ * Needs SRX_FLAG_KEEP_TENSORS.  `bytes` must be C*H*W*2.  Synchronous. */
+srx_status srx_read_tensor(srx_ctx* ctx, uint32_t frame, int32_t tensor_id,
+                           void* fp16_chw_out, size_t bytes);
+srx_status srx_tensor_shape(const srx_ctx* ctx, int32_t tensor_id,
+                            uint32_t* c, uint32_t* h, uint32_t* w);
+
+/* Host-only (no GPU needed): parse weights.bin and return the folded, truncated
+ * fp16 filter (OIHW) and bias of conv layer 0..6 exactly as
+ * ML::Util::CreateWeightTensors produces them
+ * (XUSG/MachineLearning/XUSGMachineLearning.h:856-858, called at
+ * Content/SuperResolution.cpp:318).  Either output may be NULL to query sizes;
+ * layer 6 has no bias (*bias_n = 0).  Sizes are in elements. */
+srx_status srx_fold_weights(const char* weights_path, int32_t layer, uint16_t* filter_out,
+                            size_t filter_cap, uint16_t* bias_out, size_t bias_cap,
+                            size_t* filter_n, size_t* bias_n);
+
+/* Host-only: the same layer's filter re-laid out as MFMA A-operand fragments,
+ * [tile][kstep][lane 0..63][8 halfs], as the kernels read it (the counterpart
+ * of DirectML re-formatting managed weights at operator initialisation,
+ * Content/SuperResolution.cpp:615-627).  packed_out may be NULL to query *n. */
+srx_status srx_packed_weights(const char* weights_path, int32_t layer, uint16_t* packed_out,
+                              size_t cap, size_t* n);
+
+/* Profiling hooks used by bench.py: number of kernels one srx_upscale()
+ * launches per batch chunk, their names, and a launch of stage `i` alone. */
+int32_t     srx_num_stages(const srx_ctx* ctx);
+const char* srx_stage_name(const srx_ctx* ctx, int32_t i);
+srx_status  srx_launch_stage(srx_ctx* ctx, int32_t i, void* stream);
+
+/* Message of the last failure on this thread (never NULL). */
+const char* srx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

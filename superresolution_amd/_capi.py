@@ -1,0 +1,208 @@
+"""ctypes binding of libsrx.so (include/srx.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ASSETS_DIR = os.path.join(HERE, "Assets")
+FLAG_KEEP_TENSORS = 1
+FLAG_VERBOSE_WEIGHTS = 2
+TENSOR_NAMES = ["input", "conv1", "conv2", "conv3", "conv_up1", "conv4", "conv5", "conv6", "output"]
+
+# every symbol include/srx.h declares
+SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "srx_upload_rgba8",
+           "srx_upload_rgb8", "srx_input_device_ptr", "srx_output_device_ptr", "srx_image_to_tensor",
+           "srx_process", "srx_tensor_to_image", "srx_upscale", "srx_sync", "srx_read_tensor",
+           "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
+           "srx_launch_stage", "srx_last_error"]
+
+
+class SrxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"srx status {status}: {message}")
+        self.status = status
+
+
+def lib_path():
+    return os.path.join(HERE, "libsrx.so")
+
+
+def default_weights_path():
+    return os.path.join(ASSETS_DIR, "weights.bin")
+
+
+def build_library():
+    """Compile libsrx.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc")])
+
+
+_lib = None
+
+
+def lib():
+    """Load libsrx.so.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SrxError(-1, f"{path} is missing: run __graft_entry__.build() (make -C superresolution_amd/csrc)")
+    try:
+        # torch ships its own libamdhip64.so.7; importing it first makes this library share that
+        # runtime (same SONAME) instead of loading a second HIP runtime into the process.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(path)
+    vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_size_t
+    L.srx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, u32, u32, u32, u32]
+    L.srx_destroy.argtypes = [vp]
+    L.srx_get_out_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.srx_get_in_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.srx_upload_rgba8.argtypes = [vp, u32, vp, sz, vp]
+    L.srx_upload_rgb8.argtypes = [vp, u32, vp, sz, vp]
+    L.srx_input_device_ptr.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz)]
+    L.srx_output_device_ptr.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz)]
+    L.srx_image_to_tensor.argtypes = [vp, vp]
+    L.srx_process.argtypes = [vp, vp]
+    L.srx_tensor_to_image.argtypes = [vp, u32, vp, sz, vp]
+    L.srx_upscale.argtypes = [vp, vp]
+    L.srx_sync.argtypes = [vp, vp]
+    L.srx_read_tensor.argtypes = [vp, u32, i32, vp, sz]
+    L.srx_tensor_shape.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.srx_fold_weights.argtypes = [C.c_char_p, i32, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.srx_packed_weights.argtypes = [C.c_char_p, i32, vp, sz, C.POINTER(sz)]
+    L.srx_num_stages.argtypes = [vp]
+    L.srx_stage_name.argtypes = [vp, i32]
+    L.srx_stage_name.restype = C.c_char_p
+    L.srx_launch_stage.argtypes = [vp, i32, vp]
+    L.srx_last_error.restype = C.c_char_p
+    for name in SYMBOLS:
+        if name not in ("srx_stage_name", "srx_last_error"):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        raise SrxError(status, lib().srx_last_error().decode(errors="replace"))
+
+
+class SuperResolutionContext:
+    """One GPU's worth of the path: weights, workspace, input and output images in HBM."""
+
+    def __init__(self, width, height, batch=1, device=0, weights_path=None, flags=0):
+        self._h = C.c_void_p()
+        self._L = lib()
+        _check(self._L.srx_create(C.byref(self._h), device, (weights_path or default_weights_path()).encode(),
+                                  width, height, batch, flags))
+        self.width, self.height, self.batch, self.flags = width, height, batch, flags
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.srx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def out_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(self._L.srx_get_out_size(self._h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def upload_rgba8(self, frame, rgba, stream=None):
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        assert rgba.shape == (self.height, self.width, 4), rgba.shape
+        _check(self._L.srx_upload_rgba8(self._h, frame, rgba.ctypes.data, self.width * 4, stream))
+        _check(self._L.srx_sync(self._h, stream))
+
+    def upload_rgb8(self, frame, rgb, stream=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.shape == (self.height, self.width, 3), rgb.shape
+        _check(self._L.srx_upload_rgb8(self._h, frame, rgb.ctypes.data, self.width * 3, stream))
+
+    def input_device_ptr(self, frame):
+        p, pitch = C.c_void_p(), C.c_size_t()
+        _check(self._L.srx_input_device_ptr(self._h, frame, C.byref(p), C.byref(pitch)))
+        return p.value, pitch.value
+
+    def output_device_ptr(self, frame):
+        p, pitch = C.c_void_p(), C.c_size_t()
+        _check(self._L.srx_output_device_ptr(self._h, frame, C.byref(p), C.byref(pitch)))
+        return p.value, pitch.value
+
+    def image_to_tensor(self, stream=None):
+        _check(self._L.srx_image_to_tensor(self._h, stream))
+
+    def process(self, stream=None):
+        _check(self._L.srx_process(self._h, stream))
+
+    def upscale(self, stream=None):
+        _check(self._L.srx_upscale(self._h, stream))
+
+    def sync(self, stream=None):
+        _check(self._L.srx_sync(self._h, stream))
+
+    def tensor_to_image(self, frame=0, stream=None):
+        w, h = self.out_size
+        out = np.empty((h, w, 4), np.uint8)
+        _check(self._L.srx_tensor_to_image(self._h, frame, out.ctypes.data, w * 4, stream))
+        _check(self._L.srx_sync(self._h, stream))
+        return out
+
+    def tensor_shape(self, tid):
+        c, h, w = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(self._L.srx_tensor_shape(self._h, tid, C.byref(c), C.byref(h), C.byref(w)))
+        return c.value, h.value, w.value
+
+    def read_tensor(self, tid, frame=0):
+        shape = self.tensor_shape(tid)
+        out = np.empty(shape, np.float16)
+        _check(self._L.srx_read_tensor(self._h, frame, tid, out.ctypes.data, out.nbytes))
+        return out
+
+    def stage_names(self):
+        return [self._L.srx_stage_name(self._h, i).decode() for i in range(self._L.srx_num_stages(self._h))]
+
+    def launch_stage(self, i, stream=None):
+        _check(self._L.srx_launch_stage(self._h, i, stream))
+
+    def run(self, rgba, frame=0):
+        """Upload one RGBA8 frame, upscale, return the RGBA8 result (uint8 [2H,2W,4])."""
+        self.upload_rgba8(frame, rgba)
+        self.upscale()
+        return self.tensor_to_image(frame)
+
+
+def fold_weights(layer, weights_path=None):
+    """Host-only: folded + truncated fp16 (filter OIHW, bias or None) of conv layer 0..6."""
+    L = lib()
+    path = (weights_path or default_weights_path()).encode()
+    fn, bn = C.c_size_t(), C.c_size_t()
+    _check(L.srx_fold_weights(path, layer, None, 0, None, 0, C.byref(fn), C.byref(bn)))
+    f = np.empty(fn.value, np.uint16)
+    b = np.empty(bn.value, np.uint16)
+    _check(L.srx_fold_weights(path, layer, f.ctypes.data, f.size, b.ctypes.data if bn.value else None, b.size,
+                              None, None))
+    return f, (b if bn.value else None)
+
+
+def packed_weights(layer, weights_path=None):
+    """Host-only: the MFMA fragment layout [tile][kstep][64][8] of conv layer 0..6."""
+    L = lib()
+    path = (weights_path or default_weights_path()).encode()
+    n = C.c_size_t()
+    _check(L.srx_packed_weights(path, layer, None, 0, C.byref(n)))
+    out = np.empty(n.value, np.uint16)
+    _check(L.srx_packed_weights(path, layer, out.ctypes.data, out.size, None))
+    return out

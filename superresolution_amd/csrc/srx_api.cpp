@@ -1,0 +1,494 @@
+// C ABI of the MI355X super-resolution library (include/srx.h): context,
+// memory plan, weight upload and the launch sequence of one upscale.
+#include "../../include/srx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "srx_kernels.h"
+#include "srx_weights.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+srx_status fail(srx_status code, const std::string& msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define SRX_HIP(expr)                                                                          \
+    do {                                                                                       \
+        const hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(SRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+int roundUp(int v, int m) { return (v + m - 1) / m * m; }
+
+// Channels and resolution (1 = input grid, 2 = 2x grid) of each tensor id.
+struct TensorInfo { int channels, storedChannels, scale, border; };
+const TensorInfo kTensorInfo[SRX_T_COUNT] = {
+    {3, 4, 1, 2},     // INPUT   RGB0, read by the 5x5 conv1
+    {32, 32, 1, 1},   // CONV1
+    {64, 64, 1, 1},   // CONV2
+    {64, 64, 1, 1},   // CONV3
+    {32, 32, 2, 1},   // CONV_UP1
+    {32, 32, 2, 1},   // CONV4
+    {32, 32, 2, 1},   // CONV5
+    {3, 4, 2, 0},     // CONV6   residual (kept tensors only)
+    {3, 4, 2, 0},     // OUTPUT  sum      (kept tensors only)
+};
+
+const char* const kStageNames[] = {"image_to_tensor", "conv1", "conv2", "conv3", "conv_up1",
+                                   "conv4", "conv5", "conv6_add_unorm"};
+constexpr int kNumStages = 8;
+
+}  // namespace
+
+struct srx_ctx
+{
+    int device = 0;
+    int numCUs = 256;
+    uint32_t width = 0, height = 0, batch = 0, flags = 0;
+    uint32_t chunk = 0;                      // frames of activation workspace (<= batch)
+
+    srx::FoldedWeights folded;
+    uint16_t* wpk[srx::kNumConvLayers] = {};
+    float* bias[srx::kNumConvLayers] = {};
+
+    srx::Image input, output;
+    srx::Tensor tensor[SRX_T_COUNT];
+    size_t tensorFrameBytes[SRX_T_COUNT] = {};
+    void* tensorAlloc[SRX_T_COUNT] = {};
+    int tensorRows[SRX_T_COUNT] = {};
+
+    std::vector<void*> allocs;
+    std::vector<uint8_t> hostStage;
+
+    bool keep() const { return (flags & SRX_FLAG_KEEP_TENSORS) != 0; }
+};
+
+namespace {
+
+srx_status allocZero(srx_ctx* c, void** p, size_t bytes)
+{
+    SRX_HIP(hipMalloc(p, bytes));
+    c->allocs.push_back(*p);
+    SRX_HIP(hipMemset(*p, 0, bytes));
+    return SRX_OK;
+}
+
+std::vector<uint16_t> packLayer(const srx::FoldedWeights& folded, int l)
+{
+    const uint32_t* sz = srx::kConvLayers[l].sizes;
+    if (l == 0) return srx::PackConv1(folded.filter[l]);
+    if (l == 3) return srx::PackConvUp1Phases(folded.filter[l]);
+    return srx::PackConv3x3(folded.filter[l], int(sz[0]), int(sz[1]));
+}
+
+srx_status uploadWeights(srx_ctx* c)
+{
+    using namespace srx;
+    for (int l = 0; l < kNumConvLayers; ++l)
+    {
+        const std::vector<uint16_t> packed = packLayer(c->folded, l);
+        const int biasTiles = (l == 3) ? 4 : (int(kConvLayers[l].sizes[0]) + 31) / 32;
+
+        void* d = nullptr;
+        if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
+        SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        c->wpk[l] = static_cast<uint16_t*>(d);
+
+        // fp32 copy of the (truncated fp16) bias, one value per output row of every 32-row tile
+        std::vector<float> b(size_t(biasTiles) * 32, 0.0f);
+        for (int t = 0; t < biasTiles; ++t)
+            for (int r = 0; r < 32; ++r)
+            {
+                const int o = (l == 3) ? r : t * 32 + r;
+                if (o < int(c->folded.bias[l].size())) b[t * 32 + r] = ML::Float16ToFloat32(c->folded.bias[l][o]);
+            }
+        if (const srx_status s = allocZero(c, &d, b.size() * 4)) return s;
+        SRX_HIP(hipMemcpy(d, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        c->bias[l] = static_cast<float*>(d);
+    }
+    return SRX_OK;
+}
+
+srx_status allocTensors(srx_ctx* c)
+{
+    // Per-frame bytes of the activation workspace decide how many frames run per chunk.
+    size_t perFrame = 0;
+    for (int id = 0; id < SRX_T_COUNT; ++id)
+    {
+        const TensorInfo& ti = kTensorInfo[id];
+        if ((id == SRX_T_CONV6 || id == SRX_T_OUTPUT) && !c->keep()) continue;
+        const int w = int(c->width) * ti.scale, h = int(c->height) * ti.scale;
+        const int pitch = roundUp(w, srx::kTileW) + 2 * ti.border;
+        const int rows = roundUp(h, srx::kTileH) + 2 * ti.border;
+        c->tensor[id].channels = ti.storedChannels;
+        c->tensor[id].pitch = pitch;
+        c->tensor[id].frame = int64_t(pitch) * rows * ti.storedChannels;
+        c->tensorRows[id] = rows;
+        c->tensorFrameBytes[id] = size_t(c->tensor[id].frame) * 2;
+        if (id != SRX_T_INPUT) perFrame += c->tensorFrameBytes[id];
+    }
+    const size_t budget = size_t(48) << 30;
+    uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, budget / std::max<size_t>(perFrame, 1))));
+    if (c->keep() && chunk < c->batch)
+        return fail(SRX_ERR_NOMEM, "SRX_FLAG_KEEP_TENSORS needs the whole batch resident; reduce batch");
+    c->chunk = chunk;
+
+    for (int id = 0; id < SRX_T_COUNT; ++id)
+    {
+        if (c->tensorFrameBytes[id] == 0) continue;
+        const uint32_t frames = (id == SRX_T_INPUT) ? c->batch : chunk;
+        void* d = nullptr;
+        if (const srx_status s = allocZero(c, &d, c->tensorFrameBytes[id] * frames)) return s;
+        c->tensorAlloc[id] = d;
+        const TensorInfo& ti = kTensorInfo[id];
+        c->tensor[id].base = static_cast<uint16_t*>(d) +
+                             (size_t(ti.border) * c->tensor[id].pitch + ti.border) * ti.storedChannels;
+    }
+    return SRX_OK;
+}
+
+srx::Tensor frameOffset(const srx::Tensor& t, uint32_t frame)
+{
+    srx::Tensor r = t;
+    if (r.base) r.base += size_t(frame) * t.frame;
+    return r;
+}
+
+srx::Image frameOffset(const srx::Image& im, uint32_t frame)
+{
+    srx::Image r = im;
+    r.base += size_t(frame) * im.frame;
+    return r;
+}
+
+// Launch stage `stage` (0 = pack, 1..7 = conv layers) for frames [first, first + count).
+srx_status launchStage(srx_ctx* c, int stage, uint32_t first, uint32_t count, hipStream_t s)
+{
+    using namespace srx;
+    const int W = int(c->width), H = int(c->height);
+    if (stage == 0)
+    {
+        SRX_HIP(LaunchPack(frameOffset(c->input, first), frameOffset(c->tensor[SRX_T_INPUT], first), W, H, int(count), s));
+        return SRX_OK;
+    }
+    const int l = stage - 1;
+    ConvLaunch cl;
+    cl.batch = int(count);
+    cl.wpk = c->wpk[l];
+    cl.bias = c->bias[l];
+    static const ConvKind kinds[7] = {CONV_5X5_RGB, CONV_3X3_32_64, CONV_3X3_64_64, CONV_UP1_PHASES,
+                                      CONV_3X3_32_32, CONV_3X3_32_32, CONV_3X3_32_RGB};
+    cl.kind = kinds[l];
+    // workspace tensors are indexed by frame-in-chunk (chunks start at frame 0 of the workspace)
+    cl.in = (l == 0) ? frameOffset(c->tensor[SRX_T_INPUT], first) : c->tensor[SRX_T_INPUT + l];
+    if (l < 6) cl.out = c->tensor[SRX_T_CONV1 + l];
+    const bool hiRes = l >= 4;          // conv_up1 walks the input grid and writes the 2x grid itself
+    cl.width = hiRes ? 2 * W : W;
+    cl.height = hiRes ? 2 * H : H;
+    if (l == 6)
+    {
+        cl.x0 = frameOffset(c->tensor[SRX_T_INPUT], first);
+        cl.image = frameOffset(c->output, first);
+        if (c->keep())
+        {
+            cl.residual = c->tensor[SRX_T_CONV6];
+            cl.sum = c->tensor[SRX_T_OUTPUT];
+        }
+    }
+    SRX_HIP(LaunchConv(cl, c->numCUs, s));
+    return SRX_OK;
+}
+
+bool validCtx(const srx_ctx* c) { return c != nullptr && c->batch > 0; }
+
+}  // namespace
+
+extern "C" {
+
+const char* srx_last_error(void) { return g_lastError.c_str(); }
+
+srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
+                      uint32_t in_w, uint32_t in_h, uint32_t batch, uint32_t flags)
+{
+    if (!out) return fail(SRX_ERR_INVALID, "srx_create: out is NULL");
+    *out = nullptr;
+    if (!weights_path) return fail(SRX_ERR_INVALID, "srx_create: weights_path is NULL");
+    if (in_w == 0 || in_h == 0 || batch == 0 || in_w > 16384 || in_h > 16384)
+        return fail(SRX_ERR_INVALID, "srx_create: image size must be 1..16384 and batch >= 1");
+
+    srx::ML::WeightMapType weights;
+    if (!srx::LoadWeights(weights_path, weights, (flags & SRX_FLAG_VERBOSE_WEIGHTS) != 0))
+        return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + weights_path);
+
+    srx_ctx* c = new srx_ctx;
+    c->device = device;
+    c->width = in_w;
+    c->height = in_h;
+    c->batch = batch;
+    c->flags = flags;
+    if (!srx::FoldWeights(weights, c->folded))
+    {
+        delete c;
+        return fail(SRX_ERR_WEIGHTS, "loadWeights: a layer's filter, scale or shift tensor is missing or has the wrong size");
+    }
+
+    const auto bail = [&](srx_status s) { srx_destroy(c); return s; };
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)));
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return bail(fail(SRX_ERR_HIP, std::string("this library is built for gfx950 only; device is ") + prop.gcnArchName));
+        c->numCUs = prop.multiProcessorCount;
+    }
+
+    c->input.pitch = int64_t(in_w) * 4;
+    c->input.frame = c->input.pitch * in_h;
+    c->output.pitch = int64_t(in_w) * 8;
+    c->output.frame = c->output.pitch * in_h * 2;
+    void* d = nullptr;
+    if (const srx_status s = allocZero(c, &d, size_t(c->input.frame) * batch)) return bail(s);
+    c->input.base = static_cast<uint8_t*>(d);
+    if (const srx_status s = allocZero(c, &d, size_t(c->output.frame) * batch)) return bail(s);
+    c->output.base = static_cast<uint8_t*>(d);
+
+    if (const srx_status s = uploadWeights(c)) return bail(s);
+    if (const srx_status s = allocTensors(c)) return bail(s);
+    {
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)));
+    }
+    *out = c;
+    return SRX_OK;
+}
+
+srx_status srx_destroy(srx_ctx* c)
+{
+    if (!c) return SRX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();          // no buffer is freed while stream work is pending
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return SRX_OK;
+}
+
+srx_status srx_get_out_size(const srx_ctx* c, uint32_t* w, uint32_t* h)
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    if (w) *w = c->width << 1;      // Content/SuperResolution.cpp:50-51
+    if (h) *h = c->height << 1;
+    return SRX_OK;
+}
+
+srx_status srx_get_in_size(const srx_ctx* c, uint32_t* w, uint32_t* h, uint32_t* batch)
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    if (w) *w = c->width;
+    if (h) *h = c->height;
+    if (batch) *batch = c->batch;
+    return SRX_OK;
+}
+
+srx_status srx_upload_rgba8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream)
+{
+    if (!validCtx(c) || !host || frame >= c->batch || pitch < size_t(c->width) * 4)
+        return fail(SRX_ERR_INVALID, "srx_upload_rgba8: bad frame, pointer or pitch");
+    SRX_HIP(hipSetDevice(c->device));
+    SRX_HIP(hipMemcpy2DAsync(c->input.base + size_t(frame) * c->input.frame, size_t(c->input.pitch), host, pitch,
+                             size_t(c->width) * 4, c->height, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return SRX_OK;
+}
+
+srx_status srx_upload_rgb8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream)
+{
+    if (!validCtx(c) || !host || frame >= c->batch || pitch < size_t(c->width) * 3)
+        return fail(SRX_ERR_INVALID, "srx_upload_rgb8: bad frame, pointer or pitch");
+    SRX_HIP(hipSetDevice(c->device));
+    // expand to RGBA (alpha 255) on the host, as the loader does for 3-channel files
+    c->hostStage.resize(size_t(c->width) * c->height * 4);
+    for (uint32_t y = 0; y < c->height; ++y)
+    {
+        const uint8_t* s = host + size_t(y) * pitch;
+        uint8_t* d = c->hostStage.data() + size_t(y) * c->width * 4;
+        for (uint32_t x = 0; x < c->width; ++x)
+        {
+            d[4 * x + 0] = s[3 * x + 0];
+            d[4 * x + 1] = s[3 * x + 1];
+            d[4 * x + 2] = s[3 * x + 2];
+            d[4 * x + 3] = 255;
+        }
+    }
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+    SRX_HIP(hipMemcpyAsync(c->input.base + size_t(frame) * c->input.frame, c->hostStage.data(), c->hostStage.size(),
+                           hipMemcpyHostToDevice, st));
+    SRX_HIP(hipStreamSynchronize(st));     // the staging vector is reused by the next call
+    return SRX_OK;
+}
+
+srx_status srx_input_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch)
+{
+    if (!validCtx(c) || frame >= c->batch || !dptr) return fail(SRX_ERR_INVALID, "srx_input_device_ptr: bad argument");
+    *dptr = c->input.base + size_t(frame) * c->input.frame;
+    if (pitch) *pitch = size_t(c->input.pitch);
+    return SRX_OK;
+}
+
+srx_status srx_output_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch)
+{
+    if (!validCtx(c) || frame >= c->batch || !dptr) return fail(SRX_ERR_INVALID, "srx_output_device_ptr: bad argument");
+    *dptr = c->output.base + size_t(frame) * c->output.frame;
+    if (pitch) *pitch = size_t(c->output.pitch);
+    return SRX_OK;
+}
+
+srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    SRX_HIP(hipSetDevice(c->device));
+    return launchStage(c, 0, 0, c->batch, static_cast<hipStream_t>(stream));
+}
+
+srx_status srx_process(srx_ctx* c, void* stream)
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    SRX_HIP(hipSetDevice(c->device));
+    for (uint32_t first = 0; first < c->batch; first += c->chunk)
+    {
+        const uint32_t count = std::min(c->chunk, c->batch - first);
+        for (int stage = 1; stage < kNumStages; ++stage)
+            if (const srx_status s = launchStage(c, stage, first, count, static_cast<hipStream_t>(stream))) return s;
+    }
+    return SRX_OK;
+}
+
+srx_status srx_upscale(srx_ctx* c, void* stream)
+{
+    if (const srx_status s = srx_image_to_tensor(c, stream)) return s;
+    return srx_process(c, stream);
+}
+
+srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t pitch, void* stream)
+{
+    if (!validCtx(c) || frame >= c->batch) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: bad frame");
+    if (host && pitch < size_t(c->width) * 8) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: pitch too small");
+    SRX_HIP(hipSetDevice(c->device));
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c->keep())
+        SRX_HIP(srx::LaunchUnpack(frameOffset(c->tensor[SRX_T_OUTPUT], frame), frameOffset(c->output, frame),
+                                  int(c->width) * 2, int(c->height) * 2, 1, st));
+    if (host)
+        SRX_HIP(hipMemcpy2DAsync(host, pitch, c->output.base + size_t(frame) * c->output.frame, size_t(c->output.pitch),
+                                 size_t(c->width) * 8, size_t(c->height) * 2, hipMemcpyDeviceToHost, st));
+    return SRX_OK;
+}
+
+srx_status srx_sync(srx_ctx* c, void* stream)
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    SRX_HIP(hipSetDevice(c->device));
+    SRX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return SRX_OK;
+}
+
+srx_status srx_tensor_shape(const srx_ctx* c, int32_t id, uint32_t* ch, uint32_t* h, uint32_t* w)
+{
+    if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT) return fail(SRX_ERR_INVALID, "srx_tensor_shape: bad tensor id");
+    const TensorInfo& ti = kTensorInfo[id];
+    if (ch) *ch = uint32_t(ti.channels);
+    if (h) *h = c->height * uint32_t(ti.scale);
+    if (w) *w = c->width * uint32_t(ti.scale);
+    return SRX_OK;
+}
+
+srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, size_t bytes)
+{
+    if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT || frame >= c->batch || !out)
+        return fail(SRX_ERR_INVALID, "srx_read_tensor: bad argument");
+    if (!c->keep()) return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create");
+    const TensorInfo& ti = kTensorInfo[id];
+    const size_t H = size_t(c->height) * ti.scale, W = size_t(c->width) * ti.scale;
+    if (bytes != size_t(ti.channels) * H * W * 2) return fail(SRX_ERR_INVALID, "srx_read_tensor: bytes != C*H*W*2");
+    SRX_HIP(hipSetDevice(c->device));
+    SRX_HIP(hipDeviceSynchronize());
+    std::vector<uint16_t> raw(c->tensorFrameBytes[id] / 2);
+    SRX_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t*>(c->tensorAlloc[id]) + size_t(frame) * c->tensorFrameBytes[id],
+                      c->tensorFrameBytes[id], hipMemcpyDeviceToHost));
+    const srx::Tensor& t = c->tensor[id];
+    uint16_t* dst = static_cast<uint16_t*>(out);
+    for (int ch = 0; ch < ti.channels; ++ch)
+        for (size_t y = 0; y < H; ++y)
+            for (size_t x = 0; x < W; ++x)
+                dst[(size_t(ch) * H + y) * W + x] =
+                    raw[((y + ti.border) * t.pitch + x + ti.border) * ti.storedChannels + ch];
+    return SRX_OK;
+}
+
+srx_status srx_fold_weights(const char* path, int32_t layer, uint16_t* filter, size_t filterCap,
+                            uint16_t* bias, size_t biasCap, size_t* filterN, size_t* biasN)
+{
+    if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_fold_weights: bad argument");
+    srx::ML::WeightMapType weights;
+    srx::FoldedWeights folded;
+    if (!srx::LoadWeights(path, weights, false) || !srx::FoldWeights(weights, folded))
+        return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + path);
+    const auto& f = folded.filter[layer];
+    const auto& b = folded.bias[layer];
+    if (filterN) *filterN = f.size();
+    if (biasN) *biasN = b.size();
+    if (filter)
+    {
+        if (filterCap < f.size()) return fail(SRX_ERR_INVALID, "srx_fold_weights: filter buffer too small");
+        std::memcpy(filter, f.data(), f.size() * 2);
+    }
+    if (bias && !b.empty())
+    {
+        if (biasCap < b.size()) return fail(SRX_ERR_INVALID, "srx_fold_weights: bias buffer too small");
+        std::memcpy(bias, b.data(), b.size() * 2);
+    }
+    return SRX_OK;
+}
+
+srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n)
+{
+    if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_packed_weights: bad argument");
+    srx::ML::WeightMapType weights;
+    srx::FoldedWeights folded;
+    if (!srx::LoadWeights(path, weights, false) || !srx::FoldWeights(weights, folded))
+        return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + path);
+    const std::vector<uint16_t> packed = packLayer(folded, layer);
+    if (n) *n = packed.size();
+    if (out)
+    {
+        if (cap < packed.size()) return fail(SRX_ERR_INVALID, "srx_packed_weights: buffer too small");
+        std::memcpy(out, packed.data(), packed.size() * 2);
+    }
+    return SRX_OK;
+}
+
+int32_t srx_num_stages(const srx_ctx*) { return kNumStages; }
+
+const char* srx_stage_name(const srx_ctx*, int32_t i) { return (i >= 0 && i < kNumStages) ? kStageNames[i] : ""; }
+
+srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
+{
+    if (!validCtx(c) || i < 0 || i >= kNumStages) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
+    SRX_HIP(hipSetDevice(c->device));
+    const uint32_t count = (i == 0) ? c->batch : std::min(c->chunk, c->batch);
+    return launchStage(c, i, 0, count, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

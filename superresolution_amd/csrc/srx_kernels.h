@@ -1,0 +1,63 @@
+// Launch interface between the C-ABI layer (srx_api.cpp) and the gfx950
+// kernels (srx_kernels.hip).  Plain structs, no HIP types beyond hipStream_t.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace srx {
+
+// An activation tensor in HBM: NHWC fp16 with a zero border of `border` pixels
+// on every side and the interior padded up to whole tiles.  `base` points at
+// channel 0 of image pixel (0,0) of frame 0; pixel (y,x) of frame f is at
+// base + f*frame + (y*pitch + x)*channels (halfs), for y,x in
+// [-border, padded size + border).  Everything outside the true image stays 0:
+// that is the zero padding every convolution of the graph reads.
+struct Tensor
+{
+    uint16_t* base = nullptr;
+    int channels = 0;
+    int pitch = 0;        // pixels per row, border included
+    int64_t frame = 0;    // halfs per frame
+};
+
+// 8-bit RGBA image (input texture or output render target) in HBM.
+struct Image
+{
+    uint8_t* base = nullptr;
+    int64_t pitch = 0;    // bytes per row
+    int64_t frame = 0;    // bytes per frame
+};
+
+enum ConvKind
+{
+    CONV_5X5_RGB,     // conv1: 5x5, 4-half pixels (RGB0) -> 32, bias + ReLU
+    CONV_3X3_32_64,   // conv2
+    CONV_3X3_64_64,   // conv3
+    CONV_UP1_PHASES,  // conv_up1: four phase 3x3 64->32 filters, writes the 2x grid
+    CONV_3X3_32_32,   // conv4, conv5
+    CONV_3X3_32_RGB   // conv6: 32 -> 3, no bias / ReLU; + NN2x(input) residual add + UNORM8
+};
+
+struct ConvLaunch
+{
+    ConvKind kind;
+    Tensor in, out;
+    const uint16_t* wpk = nullptr;   // packed MFMA fragments (device)
+    const float* bias = nullptr;     // per output row of every 32-row tile (device), fp32
+    int width = 0, height = 0;       // true size of the grid the tiles walk (the INPUT grid for CONV_UP1_PHASES)
+    int batch = 1;
+    // CONV_3X3_32_RGB only
+    Tensor x0;                       // packed input tensor (RGB0), low resolution
+    Image image;                     // RGBA8 output
+    Tensor residual, sum;            // optional fp16 RGB0 taps (base == nullptr: not written)
+};
+
+hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
+hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);
+hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s);
+
+constexpr int kTileW = 32;   // output pixels per MFMA column tile
+constexpr int kTileH = 8;    // output rows per workgroup tile
+
+}  // namespace srx

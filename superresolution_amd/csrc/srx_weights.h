@@ -1,0 +1,105 @@
+// Host-side weight path of the MI355X super-resolution library: the weights.bin
+// parser, the batch-norm fold + fp16 truncation, and the re-layout of the
+// filters into MFMA operand fragments.
+//
+// Interfaces follow the reference so that its call sites read the same:
+//   LoadWeights(fpath, weightMap)          Content/LoadWeights.h:13, LoadWeights.cpp:21-93
+//   ML::Util::CreateWeightTensors(...)     XUSG/MachineLearning/XUSGMachineLearning.h:856-858
+//   ML::Util::GetStrides(...)              XUSGMachineLearning.h:860
+//   WeightsType / WeightMapType            XUSGMachineLearning.h:834-835
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace srx {
+namespace ML {
+
+using WeightsType = std::vector<float>;
+using WeightMapType = std::map<std::string, WeightsType>;
+
+enum class TensorDataType : uint32_t { UNKNOWN, FLOAT32, FLOAT16 };   // XUSGMachineLearning.h:13-24
+enum class TensorLayout : uint32_t { DEFAULT, NHWC };                  // XUSGMachineLearning.h:828-832
+
+// fp32 -> fp16 by truncation toward zero, the conversion the reference applies
+// to weights and biases (Common/Float16Compressor.h:41-57): overflow beyond
+// 65504 gives infinity, values below 2^-14 become truncated half subnormals.
+uint16_t Float32ToFloat16Trunc(float v);
+float Float16ToFloat32(uint16_t h);
+// IEEE round-to-nearest-even, used only for the summed phase weights of conv_up1.
+uint16_t Float32ToFloat16(float v);
+
+class Util
+{
+public:
+    Util(TensorDataType dataType = TensorDataType::FLOAT16, TensorLayout layout = TensorLayout::DEFAULT)
+        : m_dataType(dataType), m_layout(layout) {}
+
+    // filterSizes = {N (out), C (in), H, W}.  filter = scale[n] * w (one fp32
+    // multiply) converted to the tensor data type; bias = shift[n].  With
+    // scaleLayerName == nullptr the filter passes through and no bias is made.
+    // Returns false when a named tensor is missing or has the wrong length.
+    bool CreateWeightTensors(const WeightMapType& weights, const char* convLayerName,
+                             const char* scaleLayerName, const char* shiftLayerName,
+                             const uint32_t filterSizes[4], std::vector<uint8_t>& filterWeightsOut,
+                             std::vector<uint8_t>& biasWeightsOut) const;
+
+    static void GetStrides(const uint32_t sizes[4], TensorLayout layout, uint32_t stridesOut[4]);
+
+private:
+    TensorDataType m_dataType;
+    TensorLayout m_layout;
+};
+
+}  // namespace ML
+
+// Loads weight values from a file.  Same contract as the reference function:
+// false (and the reason on stderr) when the file cannot be opened, the count is
+// negative, a name is longer than 255 bytes or the data is short.
+bool LoadWeights(const std::string& fpath, ML::WeightMapType& weightMap, bool verbose = true);
+
+// ---------------------------------------------------------------------------
+// Layer table of the sample CNN (Content/SuperResolution.cpp:188-268).
+// ---------------------------------------------------------------------------
+struct ConvLayerDesc
+{
+    const char* conv;
+    const char* scale;   // nullptr: no batch-norm, no bias, no activation (conv6)
+    const char* shift;
+    uint32_t sizes[4];   // {out, in, kh, kw}
+};
+constexpr int kNumConvLayers = 7;           // c_numConvLayers, Content/SuperResolution.h:64
+extern const ConvLayerDesc kConvLayers[kNumConvLayers];
+
+// Folded + truncated fp16 weights of every layer (OIHW) and biases.
+struct FoldedWeights
+{
+    std::vector<uint16_t> filter[kNumConvLayers];
+    std::vector<uint16_t> bias[kNumConvLayers];   // empty for conv6
+};
+bool FoldWeights(const ML::WeightMapType& weights, FoldedWeights& out);
+
+// ---------------------------------------------------------------------------
+// MFMA operand packing.  A "fragment" is what one wave feeds v_mfma_f32_32x32x16_f16
+// as its A operand for one K-step: 64 lanes x 8 halfs, lane l holding
+// A[row = l & 31][k = 8 * (l >> 5) + j], j = 0..7.  Rows are output channels.
+// Packed arrays are [tile][kstep][lane][8].
+// ---------------------------------------------------------------------------
+// 3x3 conv, CIN multiple of 16: kstep = tap * (CIN/16) + cc, k = 16*cc + 8*h + j.
+// Output channels are padded with zero rows to a multiple of 32.
+std::vector<uint16_t> PackConv3x3(const std::vector<uint16_t>& oihw, int cout, int cin);
+// conv1 (5x5 on RGB0 pixels of 4 halfs): 7 ksteps of 4 taps x 4 channels,
+// k = 4 * (tap - 4*kstep) + channel; taps 25..27 and channel 3 are zero.
+std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw /*[32,3,5,5]*/);
+// conv_up1 in four-phase form: the 5x5 filter on the 2x nearest-neighbour
+// upsampled tensor equals, for output phase (py,px), a 3x3 filter on the
+// low-resolution tensor whose taps are sums of the 5x5 taps that read the same
+// low-resolution pixel.  Sums are formed in double and rounded once to fp16.
+// Result: tile = py*2+px, layout as PackConv3x3 with cin = 64.
+std::vector<uint16_t> PackConvUp1Phases(const std::vector<uint16_t>& oihw /*[32,64,5,5]*/);
+// The phase filters themselves, [4][32][64][3][3] fp16 (for tests).
+std::vector<uint16_t> ConvUp1PhaseFilters(const std::vector<uint16_t>& oihw);
+
+}  // namespace srx

@@ -1,0 +1,136 @@
+"""CPU tests of the shipped library's host side: the C ABI loads and exports every declared
+symbol, and its weight path (parse, fold, truncate, MFMA packing) agrees with the oracle.
+No compute entry point is called here (there is no GPU in this tier)."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import superresolution_amd as S
+from superresolution_amd import _capi
+from conftest import ASSETS, GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    L = S.lib()
+    header = open(os.path.join(ROOT, "include", "srx.h")).read()
+    declared = set(re.findall(r"\b(srx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_capi.SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "lib_path", lambda: "/nonexistent/libsrx.so")
+    with pytest.raises(S.SrxError):
+        _capi.lib()
+
+
+def test_fold_matches_oracle_and_fixture(oracle, oracle_weights):
+    g = np.load(os.path.join(GOLDEN, "weights_fp16.npz"))
+    for li, (conv, scale, shift, sizes) in enumerate(oracle.LAYERS):
+        f, b = S.fold_weights(li)
+        fo, bo = oracle_weights.create_weight_tensors(conv, scale, shift, sizes)
+        assert np.array_equal(f, fo) and np.array_equal(f, g[f"filter{li}"])
+        if bo is None:
+            assert b is None
+        else:
+            assert np.array_equal(b, bo)
+
+
+def test_weight_errors(tmp_path, capfd):
+    L = S.lib()
+    n = C.c_size_t()
+    assert L.srx_fold_weights(str(tmp_path / "nope.bin").encode(), 0, None, 0, None, 0, C.byref(n), None) == 2
+    assert "Unable to open weight file" in capfd.readouterr().err
+    assert b"loadWeights" in L.srx_last_error()
+    p = tmp_path / "neg.bin"
+    p.write_bytes(struct.pack("<i", -5))
+    assert L.srx_fold_weights(str(p).encode(), 0, None, 0, None, 0, C.byref(n), None) == 2
+    assert "Invalid weight map file" in capfd.readouterr().err
+    p = tmp_path / "long.bin"
+    p.write_bytes(struct.pack("<iI", 1, 300) + b"y" * 400)
+    assert L.srx_fold_weights(str(p).encode(), 0, None, 0, None, 0, C.byref(n), None) == 2
+    assert "name_len exceeds c_bufferLength" in capfd.readouterr().err
+    p = tmp_path / "trunc.bin"
+    p.write_bytes(struct.pack("<iI", 1, 13) + b"conv1/weights" + struct.pack("<I", 2400) + b"\0" * 100)
+    assert L.srx_fold_weights(str(p).encode(), 0, None, 0, None, 0, C.byref(n), None) == 2
+    assert "Invalid tensor data" in capfd.readouterr().err
+    # a well-formed file that lacks the layers
+    p = tmp_path / "empty.bin"
+    p.write_bytes(struct.pack("<i", 0))
+    assert L.srx_fold_weights(str(p).encode(), 0, None, 0, None, 0, C.byref(n), None) == 2
+    assert L.srx_fold_weights(S.default_weights_path().encode(), 9, None, 0, None, 0, C.byref(n), None) == 1
+    small = np.zeros(4, np.uint16)
+    assert L.srx_fold_weights(S.default_weights_path().encode(), 1, small.ctypes.data, 4, None, 0, None, None) == 1
+
+
+def _unpack3x3(packed, cout, cin):
+    """Invert the fragment layout back to OIHW."""
+    tiles, cch = (cout + 31) // 32, cin // 16
+    p = packed.reshape(tiles, 9, cch, 64, 8)
+    out = np.zeros((tiles * 32, cin, 9), np.uint16)
+    for lane in range(64):
+        o, h = lane & 31, lane >> 5
+        for j in range(8):
+            # [tile, tap, cc] -> channel 16cc + 8h + j
+            out[o::32, (8 * h + j)::16, :] = p[:, :, :, lane, j].transpose(0, 2, 1).reshape(tiles, cch, 9)
+    return out
+
+
+def test_packed_3x3_layout():
+    for li, (cout, cin) in {1: (64, 32), 2: (64, 64), 4: (32, 32), 5: (32, 32), 6: (3, 32)}.items():
+        f, _ = S.fold_weights(li)
+        packed = S.packed_weights(li)
+        tiles = (cout + 31) // 32
+        assert packed.size == tiles * 9 * (cin // 16) * 64 * 8
+        back = _unpack3x3(packed, cout, cin)
+        assert np.array_equal(back[:cout], f.reshape(cout, cin, 9))
+        assert not back[cout:].any()          # padded output rows are zero
+
+
+def test_packed_conv1_layout():
+    f, _ = S.fold_weights(0)
+    w = f.reshape(32, 3, 25)
+    p = S.packed_weights(0).reshape(7, 64, 8)
+    for s in range(7):
+        for lane in (0, 5, 31, 32, 40, 63):
+            o, h = lane & 31, lane >> 5
+            for j in range(8):
+                tap, c = 4 * s + 2 * h + (j >> 2), j & 3
+                want = w[o, c, tap] if (tap < 25 and c < 3) else 0
+                assert p[s, lane, j] == want
+
+
+def test_packed_up1_phase_filters(oracle):
+    """Phase filters = sums of the 5x5 taps that read the same low-resolution pixel, rounded once."""
+    f, _ = S.fold_weights(3)
+    w = f.view(np.float16).astype(np.float64).reshape(32, 64, 5, 5)
+    packed = S.packed_weights(3).reshape(4, -1)
+    groups = {0: [[0, 1], [2, 3], [4]], 1: [[0], [1, 2], [3, 4]]}
+    for py in range(2):
+        for px in range(2):
+            ph = np.zeros((32, 64, 3, 3))
+            for a, rows in enumerate(groups[py]):
+                for b, cols in enumerate(groups[px]):
+                    ph[:, :, a, b] = w[:, :, rows][:, :, :, cols].sum(axis=(2, 3))
+            want = ph.astype(np.float32).astype(np.float16).view(np.uint16).reshape(32, 64, 9)
+            back = _unpack3x3(packed[py * 2 + px], 32, 64)
+            assert np.array_equal(back, want)
+    # and the direct/phase equivalence itself, on exact (unrounded) sums: a 5x5 conv of the
+    # NN-upsampled signal equals the phase 3x3 conv of the low-resolution signal
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((6, 7))
+    k = rng.standard_normal((5, 5))
+    up = np.pad(np.repeat(np.repeat(x, 2, 0), 2, 1), 2)
+    direct = np.array([[(up[Y:Y + 5, X:X + 5] * k).sum() for X in range(14)] for Y in range(12)])
+    xp = np.pad(x, 1)
+    for py in range(2):
+        for px in range(2):
+            ph = np.array([[k[np.ix_(r, c)].sum() for c in groups[px]] for r in groups[py]])
+            got = np.array([[(xp[y:y + 3, xx:xx + 3] * ph).sum() for xx in range(7)] for y in range(6)])
+            assert np.allclose(got, direct[py::2, px::2])

@@ -1,0 +1,219 @@
+"""CPU tests of the oracle itself: it is only worth comparing against once it is pinned.
+
+Pins, in order of strength:
+  * fp16 truncation == the reference's Float16Compressor.h compiled from where it lies
+    (oracle/_ref; skipped where the reference tree is absent, e.g. on the GPU box),
+  * folded weights == committed fixture tests/golden/weights_fp16.npz (made with that check on),
+  * graph == committed crops / images (made after the torch-float64 cross-check),
+  * semantic spot checks of each operator against plain numpy.
+"""
+import hashlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, CASES, GOLDEN, windows
+
+
+def test_compress_matches_reference_header(oracle):
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 2 ** 32, size=2_000_000, dtype=np.uint64).astype(np.uint32)
+    edge = []
+    for e in (0, 1, 0x33000000, 0x33800000, 0x38000000, 0x387fffff, 0x38800000, 0x477fe000, 0x477fe001,
+              0x47800000, 0x7f7fffff, 0x7f800000, 0x7f800001, 0x7f801fff, 0x7f802000, 0x7fc00000, 0x7fffffff):
+        for d in range(-2, 3):
+            v = (e + d) & 0xffffffff
+            edge += [v, v | 0x80000000]
+    x = np.concatenate([bits, np.array(edge, np.uint32)]).view(np.float32)
+    ref = np.empty(x.size, np.uint16)
+    R.ref_f16_compress_array(x.ctypes.data, ref.ctypes.data, x.size)
+    assert np.array_equal(oracle.f16_compress(x), ref)
+
+
+def test_compress_is_truncation_not_rne(oracle):
+    x = np.array([1.0 + 2 ** -11 + 2 ** -12, -(1.0 + 2 ** -11 + 2 ** -12), 65504.0, 65505.0, 1e-8, 6.1e-5], np.float32)
+    got = oracle.f16_compress(x)
+    assert got[0] == 0x3c00 and got[1] == 0xbc00          # RNE would give 0x3c01
+    assert got[2] == 0x7bff and got[3] == 0x7c00            # overflow -> inf
+    assert got[4] == 0 and got[5] == int(6.1e-5 * 2 ** 24)   # flush / truncated subnormal
+
+
+def test_rne_matches_numpy(oracle):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * 8,
+                        rng.standard_normal(20000).astype(np.float32) * 1e-5,
+                        np.array([0.0, -0.0, 65504, 65519.9, 65520, 1e9, -1e9, 2 ** -24, 2 ** -25, 3 * 2 ** -26], np.float32)])
+    L = oracle.lib()
+    got = np.array([L.sro_f32_to_f16_rne(float(v)) for v in x[:30000]], np.uint16)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(got, x[:30000].astype(np.float16).view(np.uint16))
+    tail = np.array([L.sro_f32_to_f16_rne(float(v)) for v in x[-10:]], np.uint16)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(tail, x[-10:].astype(np.float16).view(np.uint16))
+    h = np.arange(0, 0x7c00, 7, dtype=np.uint16)
+    back = np.array([L.sro_f16_to_f32(int(v)) for v in h], np.float32)
+    assert np.array_equal(back, h.view(np.float16).astype(np.float32))
+
+
+def test_load_weights_inventory(oracle_weights):
+    t = oracle_weights.tensors()
+    assert len(t) == 19 and sum(v.size for v in t.values()) == 128704
+    assert t["conv1/weights"].size == 2400 and t["conv_up1/conv/weights"].size == 51200
+    assert t["conv6/weights"].size == 864 and "conv6/BatchNorm/scale" not in t
+    with open(os.path.join(ASSETS, "weights.bin"), "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest().startswith("93920fb7")
+
+
+def test_load_weights_errors(oracle, tmp_path, capfd):
+    with pytest.raises(RuntimeError):
+        oracle.Weights(str(tmp_path / "missing.bin"))
+    assert "Unable to open weight file" in capfd.readouterr().err
+    p = tmp_path / "neg.bin"
+    p.write_bytes(struct.pack("<i", -1))
+    with pytest.raises(RuntimeError):
+        oracle.Weights(str(p))
+    assert "Invalid weight map file" in capfd.readouterr().err
+    p = tmp_path / "longname.bin"
+    p.write_bytes(struct.pack("<iI", 1, 256) + b"x" * 300)
+    with pytest.raises(RuntimeError):
+        oracle.Weights(str(p))
+    assert "name_len exceeds c_bufferLength" in capfd.readouterr().err
+    p = tmp_path / "short.bin"
+    p.write_bytes(struct.pack("<iI", 1, 3) + b"abc" + struct.pack("<I", 10) + b"\0" * 8)
+    with pytest.raises(RuntimeError):
+        oracle.Weights(str(p))
+    p = tmp_path / "empty.bin"
+    p.write_bytes(struct.pack("<i", 0))
+    assert oracle.Weights(str(p)).tensors() == {}
+
+
+def test_folded_weights_match_fixture(oracle, oracle_weights):
+    g = np.load(os.path.join(GOLDEN, "weights_fp16.npz"))
+    raw = oracle_weights.tensors()
+    for li, (conv, scale, shift, sizes) in enumerate(oracle.LAYERS):
+        f, b = oracle_weights.create_weight_tensors(conv, scale, shift, sizes)
+        assert np.array_equal(f, g[f"filter{li}"])
+        if scale is None:
+            assert b is None
+            # conv6 passes through unscaled
+            assert np.array_equal(f, oracle.f16_compress(raw[conv]))
+        else:
+            assert np.array_equal(b, g[f"bias{li}"])
+            # bias is the shift itself, not shift * scale
+            assert np.array_equal(b, oracle.f16_compress(raw[shift]))
+            w = (raw[scale][:, None] * raw[conv].reshape(sizes[0], -1)).astype(np.float32)
+            assert np.array_equal(f, oracle.f16_compress(w))
+
+
+def test_nhwc_weight_order_and_strides(oracle, oracle_weights):
+    conv, scale, shift, sizes = oracle.LAYERS[1]
+    f0, _ = oracle_weights.create_weight_tensors(conv, scale, shift, sizes, layout=0)
+    f1, _ = oracle_weights.create_weight_tensors(conv, scale, shift, sizes, layout=1)
+    assert np.array_equal(f0.reshape(sizes).transpose(0, 2, 3, 1).ravel(), f1)
+    import ctypes as C
+    s = (C.c_uint32 * 4)(1, 3, 5, 7)
+    st = (C.c_uint32 * 4)()
+    oracle.lib().sro_get_strides(s, 0, st)
+    assert list(st) == [105, 35, 7, 1]
+    oracle.lib().sro_get_strides(s, 1, st)
+    assert list(st) == [105, 1, 21, 3]
+    f32, _ = oracle_weights.create_weight_tensors(conv, scale, shift, sizes, dtype=1)
+    raw = oracle_weights.tensors()
+    assert np.array_equal(f32, (raw[scale][:, None] * raw[conv].reshape(sizes[0], -1)).astype(np.float32).ravel())
+
+
+def test_pack_unpack_semantics(oracle):
+    L = oracle.lib()
+    # non-square on purpose: the plane is H*W (the shader's W*W only works for squares)
+    h, w = 5, 9
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    chw = np.empty((3, h, w), np.float32)
+    L.sro_image_to_tensor(rgba.ctypes.data, w, h, w * 4, 0, chw.ctypes.data)
+    want = (rgba[..., :3].astype(np.float32) / np.float32(255)).astype(np.float16).astype(np.float32)
+    assert np.array_equal(chw, want.transpose(2, 0, 1))
+    vals = np.array([-1.0, 0.0, 0.5 / 255, 0.49 / 255, 1.0, 7.0, np.nan, 0.5, 254.5 / 255], np.float32)
+    t = np.zeros((3, 1, vals.size), np.float32)
+    t[0, 0] = vals
+    out = np.empty((1, vals.size, 4), np.uint8)
+    L.sro_tensor_to_image(t.ctypes.data, vals.size, 1, out.ctypes.data)
+    assert list(out[0, :, 0]) == [0, 0, 1, 0, 255, 255, 0, 128, 255]
+    assert (out[..., 3] == 255).all()
+
+
+def test_conv_semantics_small(oracle, oracle_weights):
+    """conv1 of a tiny image against a direct numpy evaluation (zero padding 2, cross-correlation, bias, ReLU)."""
+    rng = np.random.default_rng(4)
+    h, w = 6, 7
+    rgba = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    m = oracle.Model(oracle_weights, 0, 0)
+    m.run(rgba, keep_tensors=True)
+    x = m.tensor(oracle.T_INPUT).astype(np.float64)
+    f, b = oracle_weights.create_weight_tensors(*oracle.LAYERS[0][:3], oracle.LAYERS[0][3])
+    wt = f.view(np.float16).astype(np.float64).reshape(32, 3, 5, 5)
+    xp = np.pad(x, ((0, 0), (2, 2), (2, 2)))
+    want = np.zeros((32, h, w))
+    for i in range(5):
+        for j in range(5):
+            want += np.einsum("oc,chw->ohw", wt[:, :, i, j], xp[:, i:i + h, j:j + w])
+    want = np.maximum(want + b.view(np.float16).astype(np.float64)[:, None, None], 0)
+    got = m.tensor(oracle.T_CONV1)
+    assert np.abs(got - want).max() <= 2e-3 * max(1.0, np.abs(want).max())
+    # upsample + add: output == fp16(NN2x(input) + conv6)
+    y = np.repeat(np.repeat(m.tensor(oracle.T_INPUT), 2, axis=1), 2, axis=2)
+    s = (m.tensor(oracle.T_CONV6) + y).astype(np.float16).astype(np.float32)
+    assert np.array_equal(m.tensor(oracle.T_OUTPUT), s)
+
+
+@pytest.mark.parametrize("case", ["sashimi128", "xiaoyao", "synthetic_64x48", "synthetic_33x21"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_graph_matches_fixture(oracle, oracle_weights, case, mode):
+    from conftest import load_png_rgba
+    tag = "direct" if mode == 0 else "phases"
+    rgba = CASES[case]()
+    m = oracle.Model(oracle_weights, 0, mode)
+    out = m.run(rgba, keep_tensors=True)
+    assert np.array_equal(out, load_png_rgba(os.path.join(GOLDEN, f"{case}_{tag}_out.png")))
+    crops = np.load(os.path.join(GOLDEN, f"{case}_{tag}_crops.npz"))
+    manifest = dict()
+    for line in open(os.path.join(GOLDEN, "MANIFEST.txt")):
+        n, t, name, shape, digest = line.split()
+        manifest[(n, t, name)] = digest
+    for tid, tname in enumerate(oracle.TENSOR_NAMES):
+        t = m.tensor(tid).astype(np.float16)
+        assert hashlib.sha256(t.tobytes()).hexdigest() == manifest[(case, tag, tname)]
+        for wname, (y, x, s) in windows(t.shape[1], t.shape[2]).items():
+            assert np.array_equal(t[:, y:y + s, x:x + s], crops[f"{tname}_{wname}"])
+
+
+def test_phase_form_stays_inside_tolerance(oracle, oracle_weights):
+    """The four-phase form of conv_up1 rounds summed weights once; its cost must stay far inside
+    the stated tolerance (2e-2 on tensors, <= 1 LSB on >= 99.9 % of 8-bit pixels)."""
+    rgba = CASES["sashimi128"]()
+    a = oracle.Model(oracle_weights, 0, 0)
+    b = oracle.Model(oracle_weights, 0, 1)
+    ia, ib = a.run(rgba, True), b.run(rgba, True)
+    for tid in range(oracle.T_CONV_UP1, oracle.T_OUTPUT + 1):
+        assert np.abs(a.tensor(tid) - b.tensor(tid)).max() <= 2e-2
+    d = np.abs(ia.astype(int) - ib.astype(int))
+    assert (d <= 1).mean() >= 0.999 and d.max() <= 1
+
+
+def test_reference_stb_decodes_like_pil(oracle):
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    import ctypes as C
+    from conftest import load_png_rgba
+    for name, ch in (("Sashimi128.png", 3), ("xiaoyao.png", 4)):
+        w, h, c, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        p = R.ref_load_image(os.path.join(ASSETS, name).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(req))
+        assert p and c.value == ch and req.value == 4
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+        R.ref_free(p)
+        assert np.array_equal(buf, load_png_rgba(os.path.join(ASSETS, name)))
