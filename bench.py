@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X super-resolution path: output megapixels/s for 1080p -> 4K.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path (image->tensor, the seven convolutions with fused
+upsample / residual add / UNORM conversion) over one batch of synthetic 1920x1080 frames that
+is already resident in HBM.  Every rank owns one GPU and its own batch (frames are
+independent: no collective on the data path); rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+OUT_MP = 4 * W * H / 1e6                       # 8.2944 output megapixels per frame
+# direct-form FLOPs (2 * MAC, unpadded channels, borders counted as full) per LR pixel
+FLOP_PER_LR_PIXEL = {"conv1": 4800, "conv2": 36864, "conv3": 73728, "conv_up1": 409600,
+                     "conv4": 73728, "conv5": 73728, "conv6_add_unorm": 6912}
+FLOP_PER_FRAME = sum(FLOP_PER_LR_PIXEL.values()) * W * H          # 1408.72 GFLOP
+PEAK_FP16_DENSE = 2.5e15                       # MI355X dense fp16 MFMA, FLOP/s
+PEAK_HBM = 8.0e12
+
+
+def synthetic_frame(seed):
+    rng = np.random.default_rng(seed)
+    noise = rng.integers(0, 256, size=(H, W, 3), dtype=np.int64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    rgb = ((noise + ((xx + yy) & 255)[..., None]) // 2).astype(np.uint8)
+    return np.concatenate([rgb, np.full((H, W, 1), 255, np.uint8)], axis=2)
+
+
+def cpu_baseline():
+    """The CPU oracle (reference graph, direct form) timed on this host on a bounded sample."""
+    from oracle import sro
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    sro.build()
+    import superresolution_amd as S
+    model = sro.Model(sro.Weights(S.default_weights_path()), 0, 0)
+    cw, ch = 960, 540
+    crop = np.ascontiguousarray(synthetic_frame(1080)[:ch, :cw])
+    model.run(crop[:64, :64].copy())                       # touch code and pages
+    t0 = time.perf_counter()
+    model.run(crop)
+    dt = time.perf_counter() - t0
+    return {"value": round(4 * cw * ch / 1e6 / dt, 4), "unit": "output megapixels/s", "cores": threads,
+            "kind": "port",
+            "sample": f"one {cw}x{ch} crop (1/4) of the synthetic 1080p frame through oracle/sr_oracle.c "
+                      f"(reference graph, direct conv_up1), OpenMP {threads} threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="1080p frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import superresolution_amd as S
+    B = args.batch
+    stream = torch.cuda.current_stream().cuda_stream or None
+    ctx = S.SuperResolutionContext(W, H, batch=B, device=local_rank)
+    # synthetic frames: a few distinct seeds per rank, repeated to fill the batch (values do not
+    # change the timing of dense MFMA work; parity on this size is covered in tests/)
+    distinct = [synthetic_frame(rank * B + i) for i in range(min(B, 4))]
+    for i in range(B):
+        ctx.upload_rgba8(i, distinct[i % len(distinct)])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.upscale(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.upscale(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+
+    # per-kernel durations, HIP events on the launch stream (one launch covers the frames of
+    # one workspace pass: 1 frame at this size)
+    names = ctx.stage_names()
+    stage_ms = {}
+    if rank == 0:
+        for i, name in enumerate(names):
+            ctx.launch_stage(i, stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.stage_reps):
+                ctx.launch_stage(i, stream)
+            e1.record()
+            e1.synchronize()
+            stage_ms[name] = e0.elapsed_time(e1) / args.stage_reps
+    barrier()
+
+    if rank == 0:
+        frames = B * world * args.steps
+        fps = frames / elapsed
+        value = fps * OUT_MP
+        frames_per_launch = B if names and False else 1
+        # frames one launch_stage() covers: the workspace chunk (1 at 1080p), except image_to_tensor
+        dom = "conv_up1"
+        dom_s = stage_ms[dom] / 1e3
+        dom_flops = FLOP_PER_LR_PIXEL[dom] * W * H * frames_per_launch
+        achieved = dom_flops / dom_s / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "output megapixels/sec (1080p->4K 2x)",
+            "value": round(value, 2),
+            "unit": "output megapixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic 1920x1080 RGB frame stream -> 3840x2160, {B} frames per GPU "
+                                   f"per step, partitioned by frame, bundled weights.bin",
+                       "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}, no collective"},
+            "frames_per_s": round(fps, 2),
+            "ms_per_frame_per_gpu": round(elapsed / args.steps / B * 1e3, 4),
+            "mfma_frac_whole_path": round(fps / world * FLOP_PER_FRAME / PEAK_FP16_DENSE, 4),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_DENSE / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_FP16_DENSE, 4), "traffic": traffic,
+                         "note": "achieved = direct-form FLOPs of conv_up1 (409600 per input pixel, 849.3 GFLOP per "
+                                 "1080p frame) / measured launch time; the kernel evaluates the equivalent "
+                                 "four-phase 3x3 form (2.78x fewer MACs)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -139,7 +140,12 @@ srx_status allocTensors(srx_ctx* c)
         c->tensorFrameBytes[id] = size_t(c->tensor[id].frame) * 2;
         if (id != SRX_T_INPUT) perFrame += c->tensorFrameBytes[id];
     }
-    const size_t budget = size_t(48) << 30;
+    // Frames resident per pass.  A large image fills the GPU on its own, and running all layers
+    // of one frame before the next keeps its activations warm in the 256 MiB Infinity Cache;
+    // small images are batched into one launch per layer.  SRX_WORKSPACE_MB overrides.
+    size_t budget = size_t(4) << 30;
+    if (const char* env = std::getenv("SRX_WORKSPACE_MB"))
+        budget = std::max<size_t>(1, std::strtoull(env, nullptr, 10)) << 20;
     uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, budget / std::max<size_t>(perFrame, 1))));
     if (c->keep() && chunk < c->batch)
         return fail(SRX_ERR_NOMEM, "SRX_FLAG_KEEP_TENSORS needs the whole batch resident; reduce batch");
