@@ -150,6 +150,9 @@ srx_status srx_packed_weights(const char* weights_path, int32_t layer, uint16_t*
 int32_t     srx_num_stages(const srx_ctx* ctx);
 const char* srx_stage_name(const srx_ctx* ctx, int32_t i);
 srx_status  srx_launch_stage(srx_ctx* ctx, int32_t i, void* stream);
+/* Frames one srx_launch_stage() of a convolution stage covers (the activation
+ * workspace holds this many frames; srx_process walks the batch in such passes). */
+uint32_t    srx_frames_per_launch(const srx_ctx* ctx);
 
 /* Message of the last failure on this thread (never NULL). */
 const char* srx_last_error(void);

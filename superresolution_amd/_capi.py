@@ -16,7 +16,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_upload_rgb8", "srx_input_device_ptr", "srx_output_device_ptr", "srx_image_to_tensor",
            "srx_process", "srx_tensor_to_image", "srx_upscale", "srx_sync", "srx_read_tensor",
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
-           "srx_launch_stage", "srx_last_error"]
+           "srx_launch_stage", "srx_frames_per_launch", "srx_last_error"]
 
 
 class SrxError(RuntimeError):
@@ -79,9 +79,11 @@ def lib():
     L.srx_stage_name.restype = C.c_char_p
     L.srx_launch_stage.argtypes = [vp, i32, vp]
     L.srx_last_error.restype = C.c_char_p
+    L.srx_frames_per_launch.argtypes = [vp]
     for name in SYMBOLS:
-        if name not in ("srx_stage_name", "srx_last_error"):
+        if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch"):
             getattr(L, name).restype = i32
+    L.srx_frames_per_launch.restype = u32
     _lib = L
     return L
 
@@ -173,6 +175,10 @@ class SuperResolutionContext:
 
     def stage_names(self):
         return [self._L.srx_stage_name(self._h, i).decode() for i in range(self._L.srx_num_stages(self._h))]
+
+    @property
+    def frames_per_launch(self):
+        return self._L.srx_frames_per_launch(self._h)
 
     def launch_stage(self, i, stream=None):
         _check(self._L.srx_launch_stage(self._h, i, stream))

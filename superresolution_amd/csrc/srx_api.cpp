@@ -34,22 +34,23 @@ srx_status fail(srx_status code, const std::string& msg)
 int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 
 // Channels and resolution (1 = input grid, 2 = 2x grid) of each tensor id.
-struct TensorInfo { int channels, storedChannels, scale, border; };
+struct TensorInfo { int channels, storedChannels, scale, border, slackRight; };
 const TensorInfo kTensorInfo[SRX_T_COUNT] = {
-    {3, 4, 1, 2},     // INPUT   RGB0, read by the 5x5 conv1
-    {32, 32, 1, 1},   // CONV1
-    {64, 64, 1, 1},   // CONV2
-    {64, 64, 1, 1},   // CONV3
-    {32, 32, 2, 1},   // CONV_UP1
-    {32, 32, 2, 1},   // CONV4
-    {32, 32, 2, 1},   // CONV5
-    {3, 4, 2, 0},     // CONV6   residual (kept tensors only)
-    {3, 4, 2, 0},     // OUTPUT  sum      (kept tensors only)
+    {3, 4, 1, 2, 0},     // INPUT   RGB0, read by the 5x5 conv1
+    {32, 32, 1, 1, 0},   // CONV1
+    {64, 64, 1, 1, 0},   // CONV2
+    {64, 64, 1, 1, 0},   // CONV3
+    {32, 32, 2, 4, 64},  // CONV_UP1 read by the fused conv4-6 kernel: 3-pixel halo, 64-pixel strips
+    {32, 32, 2, 1, 0},   // CONV4   (kept tensors only)
+    {32, 32, 2, 1, 0},   // CONV5   (kept tensors only)
+    {3, 4, 2, 0, 0},     // CONV6   residual (kept tensors only)
+    {3, 4, 2, 0, 0},     // OUTPUT  sum      (kept tensors only)
 };
 
+// One kernel launch of the upscale sequence.
+enum StageKind { ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6, ST_HR_FUSED };
 const char* const kStageNames[] = {"image_to_tensor", "conv1", "conv2", "conv3", "conv_up1",
-                                   "conv4", "conv5", "conv6_add_unorm"};
-constexpr int kNumStages = 8;
+                                   "conv4", "conv5", "conv6_add_unorm", "conv4_conv5_conv6_add_unorm"};
 
 }  // namespace
 
@@ -63,6 +64,8 @@ struct srx_ctx
     srx::FoldedWeights folded;
     uint16_t* wpk[srx::kNumConvLayers] = {};
     float* bias[srx::kNumConvLayers] = {};
+    uint16_t* wpk6Rows16 = nullptr;          // conv6 as 16x16x32 fragments (fused kernel)
+    std::vector<StageKind> stages;           // launch sequence of one upscale
 
     srx::Image input, output;
     srx::Tensor tensor[SRX_T_COUNT];
@@ -119,6 +122,13 @@ srx_status uploadWeights(srx_ctx* c)
         SRX_HIP(hipMemcpy(d, b.data(), b.size() * 4, hipMemcpyHostToDevice));
         c->bias[l] = static_cast<float*>(d);
     }
+    {
+        const std::vector<uint16_t> packed = PackConv3x3Rows16(c->folded.filter[6], 3, 32);
+        void* d = nullptr;
+        if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
+        SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        c->wpk6Rows16 = static_cast<uint16_t*>(d);
+    }
     return SRX_OK;
 }
 
@@ -129,9 +139,9 @@ srx_status allocTensors(srx_ctx* c)
     for (int id = 0; id < SRX_T_COUNT; ++id)
     {
         const TensorInfo& ti = kTensorInfo[id];
-        if ((id == SRX_T_CONV6 || id == SRX_T_OUTPUT) && !c->keep()) continue;
+        if (id >= SRX_T_CONV4 && !c->keep()) continue;   // never materialised by the fused kernel
         const int w = int(c->width) * ti.scale, h = int(c->height) * ti.scale;
-        const int pitch = roundUp(w, srx::kTileW) + 2 * ti.border;
+        const int pitch = roundUp(w, srx::kTileW) + 2 * ti.border + ti.slackRight;
         const int rows = roundUp(h, srx::kTileH) + 2 * ti.border;
         c->tensor[id].channels = ti.storedChannels;
         c->tensor[id].pitch = pitch;
@@ -179,17 +189,34 @@ srx::Image frameOffset(const srx::Image& im, uint32_t frame)
     return r;
 }
 
-// Launch stage `stage` (0 = pack, 1..7 = conv layers) for frames [first, first + count).
-srx_status launchStage(srx_ctx* c, int stage, uint32_t first, uint32_t count, hipStream_t s)
+// Launch one stage for frames [first, first + count).
+srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t count, hipStream_t s)
 {
     using namespace srx;
     const int W = int(c->width), H = int(c->height);
-    if (stage == 0)
+    if (stage == ST_PACK)
     {
         SRX_HIP(LaunchPack(frameOffset(c->input, first), frameOffset(c->tensor[SRX_T_INPUT], first), W, H, int(count), s));
         return SRX_OK;
     }
-    const int l = stage - 1;
+    if (stage == ST_HR_FUSED)
+    {
+        HrFusedLaunch hl;
+        hl.a4 = c->tensor[SRX_T_CONV_UP1];
+        hl.x0 = frameOffset(c->tensor[SRX_T_INPUT], first);
+        hl.wpk4 = c->wpk[4];
+        hl.wpk5 = c->wpk[5];
+        hl.wpk6 = c->wpk6Rows16;
+        hl.bias4 = c->bias[4];
+        hl.bias5 = c->bias[5];
+        hl.image = frameOffset(c->output, first);
+        hl.width2 = 2 * W;
+        hl.height2 = 2 * H;
+        hl.batch = int(count);
+        SRX_HIP(LaunchHrFused(hl, c->numCUs, s));
+        return SRX_OK;
+    }
+    const int l = int(stage) - int(ST_CONV1);
     ConvLaunch cl;
     cl.batch = int(count);
     cl.wpk = c->wpk[l];
@@ -272,6 +299,10 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (const srx_status s = allocZero(c, &d, size_t(c->output.frame) * batch)) return bail(s);
     c->output.base = static_cast<uint8_t*>(d);
 
+    if (c->keep())
+        c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6};
+    else
+        c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_HR_FUSED};
     if (const srx_status s = uploadWeights(c)) return bail(s);
     if (const srx_status s = allocTensors(c)) return bail(s);
     {
@@ -365,7 +396,7 @@ srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
-    return launchStage(c, 0, 0, c->batch, static_cast<hipStream_t>(stream));
+    return launchStage(c, ST_PACK, 0, c->batch, static_cast<hipStream_t>(stream));
 }
 
 srx_status srx_process(srx_ctx* c, void* stream)
@@ -375,8 +406,8 @@ srx_status srx_process(srx_ctx* c, void* stream)
     for (uint32_t first = 0; first < c->batch; first += c->chunk)
     {
         const uint32_t count = std::min(c->chunk, c->batch - first);
-        for (int stage = 1; stage < kNumStages; ++stage)
-            if (const srx_status s = launchStage(c, stage, first, count, static_cast<hipStream_t>(stream))) return s;
+        for (size_t i = 1; i < c->stages.size(); ++i)
+            if (const srx_status s = launchStage(c, c->stages[i], first, count, static_cast<hipStream_t>(stream))) return s;
     }
     return SRX_OK;
 }
@@ -485,16 +516,21 @@ srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, si
     return SRX_OK;
 }
 
-int32_t srx_num_stages(const srx_ctx*) { return kNumStages; }
+int32_t srx_num_stages(const srx_ctx* c) { return validCtx(c) ? int32_t(c->stages.size()) : 0; }
 
-const char* srx_stage_name(const srx_ctx*, int32_t i) { return (i >= 0 && i < kNumStages) ? kStageNames[i] : ""; }
+const char* srx_stage_name(const srx_ctx* c, int32_t i)
+{
+    return (validCtx(c) && i >= 0 && i < int32_t(c->stages.size())) ? kStageNames[c->stages[size_t(i)]] : "";
+}
+
+uint32_t srx_frames_per_launch(const srx_ctx* c) { return validCtx(c) ? std::min(c->chunk, c->batch) : 0; }
 
 srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
 {
-    if (!validCtx(c) || i < 0 || i >= kNumStages) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
+    if (!validCtx(c) || i < 0 || i >= int32_t(c->stages.size())) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
     SRX_HIP(hipSetDevice(c->device));
     const uint32_t count = (i == 0) ? c->batch : std::min(c->chunk, c->batch);
-    return launchStage(c, i, 0, count, static_cast<hipStream_t>(stream));
+    return launchStage(c, c->stages[size_t(i)], 0, count, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -53,6 +53,19 @@ struct ConvLaunch
     Tensor residual, sum;            // optional fp16 RGB0 taps (base == nullptr: not written)
 };
 
+// conv4 + conv5 + conv6 + residual add + UNORM8 in one kernel (rolling row window in LDS).
+// a4 needs a border of at least 3 pixels and 64 pixels of slack to the right of the padded width.
+struct HrFusedLaunch
+{
+    Tensor a4, x0;
+    const uint16_t *wpk4 = nullptr, *wpk5 = nullptr, *wpk6 = nullptr;   // wpk6: 16x16x32 fragments
+    const float *bias4 = nullptr, *bias5 = nullptr;
+    Image image;
+    int width2 = 0, height2 = 0;     // size of the 2x grid
+    int batch = 1;
+};
+hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s);
+
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s);

@@ -280,6 +280,20 @@ std::vector<uint16_t> PackConv3x3(const std::vector<uint16_t>& oihw, int cout, i
     return out;
 }
 
+std::vector<uint16_t> PackConv3x3Rows16(const std::vector<uint16_t>& oihw, int cout, int cin)
+{
+    std::vector<uint16_t> out(size_t(9) * 64 * 8, 0);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+        {
+            const int o = lane & 15, q = lane >> 4;
+            if (o >= cout) continue;
+            for (int j = 0; j < 8; ++j)
+                out[(size_t(tap) * 64 + lane) * 8 + j] = oihw[(size_t(o) * cin + 8 * q + j) * 9 + tap];
+        }
+    return out;
+}
+
 std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw)
 {
     constexpr int ksteps = 7;

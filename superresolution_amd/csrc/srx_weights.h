@@ -90,6 +90,10 @@ bool FoldWeights(const ML::WeightMapType& weights, FoldedWeights& out);
 // 3x3 conv, CIN multiple of 16: kstep = tap * (CIN/16) + cc, k = 16*cc + 8*h + j.
 // Output channels are padded with zero rows to a multiple of 32.
 std::vector<uint16_t> PackConv3x3(const std::vector<uint16_t>& oihw, int cout, int cin);
+// Same filter as fragments of v_mfma_f32_16x16x32_f16: lane l holds
+// A[row = l & 15][k = 8 * (l >> 4) + j]; one kstep per tap covers 32 input channels;
+// output channels are padded with zero rows to 16.  Layout [tap][lane][8].
+std::vector<uint16_t> PackConv3x3Rows16(const std::vector<uint16_t>& oihw, int cout, int cin /* == 32 */);
 // conv1 (5x5 on RGB0 pixels of 4 halfs): 7 ksteps of 4 taps x 4 channels,
 // k = 4 * (tap - 4*kstep) + channel; taps 25..27 and channel 3 are zero.
 std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw /*[32,3,5,5]*/);

@@ -81,13 +81,18 @@ def test_against_golden_fixtures(case):
                     assert np.abs(t[:, y:y + s, x:x + s] - want).max() <= (0 if tid == 0 else TENSOR_TOL)
 
 
-def test_fast_path_matches_kept_tensor_path():
-    """Without SRX_FLAG_KEEP_TENSORS the same kernels run; the image must be identical."""
-    rgba = CASES["xiaoyao"]()
+@pytest.mark.parametrize("case", ["xiaoyao", "sashimi", "synthetic_33x21"])
+def test_fused_path_matches_layerwise_path(phases_model, case):
+    """Without SRX_FLAG_KEEP_TENSORS conv4..conv6 run fused (rolling rows in LDS, conv6 on the
+    16x16x32 MFMA): same arithmetic up to the order of the fp32 sums inside conv6."""
+    rgba = CASES[case]()
     h, w = rgba.shape[:2]
     with S.SuperResolutionContext(w, h, flags=S.FLAG_KEEP_TENSORS) as a, S.SuperResolutionContext(w, h) as b:
+        assert "conv4_conv5_conv6_add_unorm" in b.stage_names() and "conv4" in a.stage_names()
         ia, ib = a.run(rgba), b.run(rgba)
-        assert np.array_equal(ia, ib)
+        d = np.abs(ia.astype(int) - ib.astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.995
+        check_image(ib, phases_model.run(rgba))
         with pytest.raises(S.SrxError):
             b.read_tensor(1)
 
