@@ -1,0 +1,280 @@
+#include "SuperResolutionX.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cassert>
+#include <ctime>
+#include <cwctype>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "ImageIO.h"
+
+using namespace std;
+
+namespace {
+// The reference turns a failed bool into ThrowIfFailed(E_FAIL) -> HrException
+// (Common/DXFrameworkHelper.h:27-44); here the same failures surface as runtime_error.
+void ThrowIfFailed(bool ok, const char* what)
+{
+    if (!ok) throw std::runtime_error(what);
+}
+}  // namespace
+
+SuperResolutionX::SuperResolutionX(uint32_t width, uint32_t height, std::wstring name) :
+    DXFramework(width, height, name),
+    m_vendorId(0x1002),
+    m_deviceIndex(0),
+    m_stream(nullptr),
+    m_frameIndex(0),
+    m_deviceType(DEVICE_DISCRETE),
+    m_updateImage(false),
+    m_showFPS(true),
+    m_pausing(false),
+    m_isFirstFrame(true),
+    m_fileName("Assets/Sashimi128.png"),
+    m_screenShot(0),
+    m_frameCnt(0),
+    m_lastFps(0.0)
+{
+}
+
+SuperResolutionX::~SuperResolutionX()
+{
+}
+
+void SuperResolutionX::OnInit()
+{
+    LoadPipeline();
+    LoadAssets();
+}
+
+// Load the rendering pipeline dependencies: pick the device, create the stream, build the model,
+// size the render targets to the 2x output.
+void SuperResolutionX::LoadPipeline()
+{
+    // The reference's -warp switch selects the Windows software rasteriser.  There is no software
+    // adapter here: the library refuses to run without a gfx950 GPU rather than fall back.
+    if (m_deviceType == DEVICE_WARP)
+        throw std::runtime_error("-warp: no software adapter exists in the HIP build; run on an MI355X");
+
+    int count = 0;
+    ThrowIfFailed(hipGetDeviceCount(&count) == hipSuccess && count > 0, "no HIP device found");
+    ThrowIfFailed(m_deviceIndex >= 0 && m_deviceIndex < count, "device index out of range");
+    ThrowIfFailed(hipSetDevice(m_deviceIndex) == hipSuccess, "hipSetDevice failed");
+    hipStream_t stream = nullptr;
+    ThrowIfFailed(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess, "hipStreamCreate failed");
+    m_stream = stream;
+
+    ThrowIfFailed(InitTensors(), "InitTensors failed");
+    m_width = m_superResolution->GetOutWidth();
+    m_height = m_superResolution->GetOutHeight();
+
+    // Create frame resources: one render target per frame in flight.
+    for (uint8_t n = 0; n < FrameCount; ++n) m_renderTargets[n].Create(m_width, m_height);
+}
+
+// Load the sample assets: wait until the uploads of Init have reached the GPU.
+void SuperResolutionX::LoadAssets()
+{
+    WaitForGpu();
+    m_startTime = m_statsTime = chrono::steady_clock::now();
+}
+
+bool SuperResolutionX::InitTensors()
+{
+    m_superResolution = make_unique<SuperResolution>();
+    // fp16 tensors are always supported on gfx950 (the reference queries DirectML for this)
+    return m_superResolution->Init(m_stream, m_deviceIndex, m_vendorId, m_fileName.c_str(), true);
+}
+
+// Update frame-based values.
+void SuperResolutionX::OnUpdate()
+{
+    CalculateFrameStats();
+}
+
+// Render the scene.
+void SuperResolutionX::OnRender()
+{
+    // Record and submit all the work of this frame.
+    PopulateCommandList();
+
+    // "Present": the frame now sits in its render target.
+    MoveToNextFrame();
+}
+
+void SuperResolutionX::OnDestroy()
+{
+    // Ensure that the GPU is no longer referencing resources that are about to be
+    // cleaned up by the destructor.
+    WaitForGpu();
+    m_superResolution.reset();
+    if (m_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(m_stream));
+    m_stream = nullptr;
+}
+
+// User hot-key interactions.
+void SuperResolutionX::OnKeyUp(uint8_t key)
+{
+    switch (key)
+    {
+    case VK_SPACE:
+        m_pausing = !m_pausing;
+        break;
+    case VK_F1:
+        m_showFPS = !m_showFPS;
+        break;
+    case VK_F11:
+        m_screenShot = 1;
+        break;
+    case 'U':
+        m_updateImage = !m_updateImage;
+        break;
+    }
+}
+
+void SuperResolutionX::ParseCommandLineArgs(wchar_t* argv[], int argc)
+{
+    const auto lower = [](wstring s)
+    {
+        transform(s.begin(), s.end(), s.begin(), [](wchar_t c) { return towlower(c); });
+        return s;
+    };
+    // a switch starts with '-' or '/', and matches case-insensitively
+    const auto isSwitch = [&](int i, const wchar_t* name)
+    {
+        const wchar_t* arg = argv[i];
+        return (arg[0] == L'-' || arg[0] == L'/') && lower(arg + 1) == lower(name);
+    };
+    // a value is anything that is not itself a switch; "-1" and "-.5" count as values
+    const auto hasValue = [&](int i)
+    {
+        if (i + 1 >= argc) return false;
+        const wchar_t* arg = argv[i + 1];
+        if (arg[0] == L'/') return false;
+        return arg[0] != L'-' || (arg[1] >= L'0' && arg[1] <= L'9') || arg[1] == L'.';
+    };
+
+    DXFramework::ParseCommandLineArgs(argv, argc);
+
+    for (int i = 1; i < argc; ++i)
+    {
+        if (isSwitch(i, L"warp")) m_deviceType = DEVICE_WARP;
+        else if (isSwitch(i, L"uma")) m_deviceType = DEVICE_UMA;      // accepted; one kind of device here
+        else if ((isSwitch(i, L"i") || isSwitch(i, L"image")) && hasValue(i))
+        {
+            const wstring value = argv[++i];
+            m_fileName.assign(value.size(), '\0');
+            for (size_t j = 0; j < value.size(); ++j) m_fileName[j] = static_cast<char>(value[j]);
+        }
+    }
+}
+
+void SuperResolutionX::PopulateCommandList()
+{
+    if (m_isFirstFrame || m_updateImage)
+    {
+        m_superResolution->ImageToTensors(m_stream);
+        m_superResolution->Process(m_stream);
+        m_isFirstFrame = false;
+    }
+
+    RenderTarget* pRenderTarget = &m_renderTargets[m_frameIndex];
+    m_superResolution->Render(m_stream, pRenderTarget);
+
+    // Screen-shot helper
+    if (m_screenShot == 1)
+    {
+        WaitForGpu();
+        m_readBuffer = *pRenderTarget;
+        m_screenShot = 2;
+    }
+}
+
+// Wait for pending GPU work to complete.
+void SuperResolutionX::WaitForGpu()
+{
+    ThrowIfFailed(hipStreamSynchronize(static_cast<hipStream_t>(m_stream)) == hipSuccess, "hipStreamSynchronize failed");
+}
+
+// Prepare to render the next frame.
+void SuperResolutionX::MoveToNextFrame()
+{
+    // One in-order stream: a render target is reusable once the copy into it has completed.
+    WaitForGpu();
+    m_frameIndex = (m_frameIndex + 1) % FrameCount;
+
+    // Screen-shot helper: the reference saves FrameCount frames after the request
+    if (m_screenShot)
+    {
+        if (m_screenShot > FrameCount)
+        {
+            char timeStr[15];
+            tm dateTime;
+            const auto now = time(nullptr);
+            if (localtime_r(&now, &dateTime) && strftime(timeStr, sizeof(timeStr), "%Y%m%d%H%M%S", &dateTime))
+                SaveImage((string("SuperResolutionX_") + timeStr + ".png").c_str(), &m_readBuffer, m_width, m_height,
+                          m_readBuffer.rowPitch);
+            m_screenShot = 0;
+        }
+        else ++m_screenShot;
+    }
+}
+
+void SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
+                                 uint32_t rowPitch, uint8_t comp)
+{
+    assert(comp == 3 || comp == 4);
+    const uint8_t* pData = pImageBuffer->pixels.data();
+
+    // strip the row pitch and (comp == 3) the alpha channel
+    vector<uint8_t> imageData(size_t(comp) * w * h);
+    for (uint32_t i = 0; i < h; ++i)
+        for (uint32_t j = 0; j < w; ++j)
+            for (uint8_t k = 0; k < comp; ++k)
+                imageData[(size_t(w) * i + j) * comp + k] = pData[size_t(rowPitch) * i + 4 * j + k];
+
+    if (!srx::WritePng(fileName, int(w), int(h), comp, imageData.data(), 0))
+        cerr << "SaveImage: " << srx::LastImageError() << endl;
+    else cout << "Saved " << fileName << endl;
+}
+
+bool SuperResolutionX::SaveFrame(const char* fileName)
+{
+    const uint32_t last = (m_frameIndex + FrameCount - 1) % FrameCount;
+    SaveImage(fileName, &m_renderTargets[last], m_width, m_height, m_renderTargets[last].rowPitch);
+    return true;
+}
+
+double SuperResolutionX::CalculateFrameStats(float* pTimeStep)
+{
+    const auto now = chrono::steady_clock::now();
+    const double totalTime = chrono::duration<double>(now - m_startTime).count();
+    ++m_frameCnt;
+
+    const double timeStep = chrono::duration<double>(now - m_statsTime).count();
+
+    // Compute averages over one second period.
+    if (timeStep >= 1.0)
+    {
+        m_lastFps = m_frameCnt / timeStep;
+        m_frameCnt = 0;
+        m_statsTime = now;
+
+        wstringstream windowText;
+        windowText << L"    fps: ";
+        if (m_showFPS) windowText << setprecision(2) << fixed << m_lastFps;
+        else windowText << L"[F1]";
+        windowText << L"    [F11] screen shot";
+        SetCustomWindowText(windowText.str().c_str());
+    }
+
+    if (pTimeStep) *pTimeStep = static_cast<float>(timeStep);
+
+    return totalTime;
+}

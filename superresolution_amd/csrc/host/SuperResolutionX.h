@@ -1,0 +1,87 @@
+// The application class of the sample, headless.  Public interface as in the
+// reference (SuperResolutionX.h:26-39): constructor (width, height, name) and the
+// DXFramework overrides OnInit / OnUpdate / OnRender / OnDestroy / OnKeyUp /
+// ParseCommandLineArgs.  The D3D12 device, swap chain, command allocators and
+// fence of the reference become: a HIP device index, FrameCount host render
+// targets, and an in-order HIP stream that is drained where the reference waits
+// on its fence.
+#pragma once
+
+#include <chrono>
+#include <memory>
+#include <string>
+
+#include "DXFramework.h"
+#include "SuperResolution.h"
+
+class SuperResolutionX : public DXFramework
+{
+public:
+    SuperResolutionX(uint32_t width, uint32_t height, std::wstring name);
+    virtual ~SuperResolutionX();
+
+    virtual void OnInit();
+    virtual void OnUpdate();
+    virtual void OnRender();
+    virtual void OnDestroy();
+
+    virtual void OnKeyUp(uint8_t /*key*/);
+
+    virtual void ParseCommandLineArgs(wchar_t* argv[], int argc);
+
+    // Headless additions: which GPU to use, and a direct save of the last rendered frame.
+    void SetDeviceIndex(int device) { m_deviceIndex = device; }
+    bool SaveFrame(const char* fileName);
+    double GetLastFps() const { return m_lastFps; }
+
+private:
+    enum DeviceType : uint8_t
+    {
+        DEVICE_DISCRETE,
+        DEVICE_UMA,
+        DEVICE_WARP
+    };
+
+    static const uint8_t FrameCount = 3;
+
+    RenderTarget m_renderTargets[FrameCount];
+
+    std::unique_ptr<SuperResolution> m_superResolution;
+
+    uint32_t m_vendorId;
+    int m_deviceIndex;
+    void* m_stream;
+
+    // Synchronization objects.
+    uint32_t m_frameIndex;
+
+    // Application state
+    DeviceType m_deviceType;
+    bool m_updateImage;
+    bool m_showFPS;
+    bool m_pausing;
+    bool m_isFirstFrame;
+
+    // User external settings
+    std::string m_fileName;
+
+    // Screen-shot helpers and state
+    RenderTarget m_readBuffer;
+    uint8_t m_screenShot;
+
+    // frame statistics
+    std::chrono::steady_clock::time_point m_startTime, m_statsTime;
+    uint32_t m_frameCnt;
+    double m_lastFps;
+
+    void LoadPipeline();
+    void LoadAssets();
+    bool InitTensors();
+
+    void PopulateCommandList();
+    void WaitForGpu();
+    void MoveToNextFrame();
+    void SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
+                   uint32_t rowPitch, uint8_t comp = 3);
+    double CalculateFrameStats(float* fTimeStep = nullptr);
+};

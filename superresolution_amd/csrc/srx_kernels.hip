@@ -177,6 +177,18 @@ __global__ __launch_bounds__(kThreads, 2) void Conv3x3Kernel(const ConvParams p)
                 const f16x8 b = *reinterpret_cast<const f16x8*>(base + (i * LW + j) * STRIDE + cc * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], b, acc, 0, 0, 0);
             }
+            // keep several LDS reads in flight ahead of the MFMA that consumes them
+            {
+                constexpr int kAhead = 6;
+                __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+                for (int k = 0; k < KSTEPS - kAhead; ++k)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
+            }
 
             // D layout: column = lane & 31 (pixel), row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
             const int y = ty * TH + r;

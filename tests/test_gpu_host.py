@@ -1,0 +1,74 @@
+"""GPU tests of the headless host program (superresolution_amd/srx_main): the SuperResolutionX /
+SuperResolution classes driven through ParseCommandLineArgs -> OnInit -> {OnUpdate, OnRender}* ->
+OnDestroy, as the reference's window loop drives them."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import superresolution_amd as S
+from conftest import ASSETS, GOLDEN, ROOT, load_png_rgba
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "superresolution_amd", "srx_main")
+
+
+def run(args, cwd):
+    return subprocess.run([EXE] + args, cwd=cwd, capture_output=True, text=True, timeout=120)
+
+
+@pytest.fixture
+def workdir(tmp_path):
+    os.symlink(ASSETS, tmp_path / "Assets")       # weights and images are found relative to the CWD
+    return tmp_path
+
+
+def test_default_image_and_screenshot(workdir):
+    """No arguments: Assets/Sashimi128.png, and the F11 path writes SuperResolutionX_<timestamp>.png (RGB)."""
+    r = run([], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "Number of weight tensors: 19" in r.stdout and "Loaded tensor: conv1/weights -> 2400" in r.stdout
+    assert "output 256x256" in r.stdout
+    shots = glob.glob(str(workdir / "SuperResolutionX_*.png"))
+    assert len(shots) == 1
+    im = Image.open(shots[0])
+    assert im.mode == "RGB" and im.size == (256, 256)
+    got = np.asarray(im)
+    with S.SuperResolutionContext(128, 128) as ctx:
+        want = ctx.run(load_png_rgba(os.path.join(ASSETS, "Sashimi128.png")))
+    assert np.array_equal(got, want[..., :3])
+    ref = load_png_rgba(os.path.join(GOLDEN, "sashimi128_phases_out.png"))
+    assert np.abs(got.astype(int) - ref[..., :3].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("flag", ["-i", "/IMAGE", "-Image"])
+def test_image_switch_spellings(workdir, flag):
+    r = run([flag, "Assets/xiaoyao.png", "-o", "out.png", "-uma"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "output 182x182" in r.stdout
+    got = np.asarray(Image.open(workdir / "out.png"))
+    ref = load_png_rgba(os.path.join(GOLDEN, "xiaoyao_phases_out.png"))
+    assert got.shape == (182, 182, 3)
+    assert np.abs(got.astype(int) - ref[..., :3].astype(int)).max() <= 1
+
+
+def test_update_mode_reruns_inference(workdir):
+    r = run(["-i", "Assets/Sashimi.png", "-update", "-frames", "8", "-o", "o.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert np.asarray(Image.open(workdir / "o.png")).shape == (512, 512, 3)
+
+
+def test_failures_are_loud(workdir, tmp_path):
+    r = run(["-warp"], workdir)
+    assert r.returncode != 0 and "no software adapter" in r.stderr
+    r = run(["-i", "Assets/missing.png"], workdir)
+    assert r.returncode != 0 and "Unable to load image" in r.stderr
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    os.makedirs(empty / "Assets")
+    os.symlink(os.path.join(ASSETS, "Sashimi128.png"), empty / "Assets" / "Sashimi128.png")
+    r = run([], empty)                         # weights.bin missing -> loadWeights
+    assert r.returncode != 0 and "Unable to open weight file" in r.stderr and "loadWeights" in r.stderr

@@ -1,0 +1,139 @@
+"""CPU tests of the host program's PNG codec (superresolution_amd/csrc/host/ImageIO.cpp) against
+PIL and, where oracle/_ref exists, against the reference's own stb_image compiled in place.
+The contract is the decoded pixels and the channel rule of XUSG/Advanced/XUSGTextureLoader.h:17-32
+(3-channel files load as RGBA, other channel counts load as they are)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import ASSETS, ROOT
+
+LIB = os.path.join(ROOT, "superresolution_amd", "libsrximage.so")
+
+
+@pytest.fixture(scope="module")
+def img():
+    if not os.path.exists(LIB):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "superresolution_amd", "csrc", "host"), "../../libsrximage.so"])
+    L = C.CDLL(LIB)
+    L.srx_image_last_error.restype = C.c_char_p
+    L.srx_image_info.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4
+    L.srx_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+    L.srx_image_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    return L
+
+
+def load(L, path):
+    w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.srx_image_info(str(path).encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(req)) == 0, L.srx_image_last_error()
+    out = np.empty((h.value, w.value, req.value), np.uint8)
+    assert L.srx_image_load(str(path).encode(), out.ctypes.data, out.nbytes) == 0, L.srx_image_last_error()
+    return out, ch.value, req.value
+
+
+@pytest.mark.parametrize("name,channels", [("Sashimi128.png", 3), ("Sashimi.png", 3), ("xiaoyao.png", 4)])
+def test_bundled_images(img, oracle, name, channels):
+    path = os.path.join(ASSETS, name)
+    got, ch, req = load(img, path)
+    assert ch == channels and req == 4
+    assert np.array_equal(got, np.asarray(Image.open(path).convert("RGBA")))
+    R = oracle.ref()
+    if R is not None:     # the reference's stb_image v2.30, compiled from where it lies
+        w, h, c, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        p = R.ref_load_image(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(r))
+        ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, r.value)).copy()
+        R.ref_free(p)
+        assert c.value == ch and r.value == req and np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("mode,kw", [("L", {}), ("LA", {}), ("RGB", {}), ("RGBA", {}), ("P", {}), ("RGB", {"interlace": True}),
+                                     ("I;16", {}), ("1", {})])
+def test_png_flavours(img, oracle, tmp_path, mode, kw):
+    rng = np.random.default_rng(7)
+    h, w = 37, 53
+    if mode == "I;16":
+        im = Image.fromarray(rng.integers(0, 65536, size=(h, w), dtype=np.uint16))
+    elif mode == "1":
+        im = Image.fromarray((rng.integers(0, 2, size=(h, w)) * 255).astype(np.uint8)).convert("1")
+    elif mode == "P":
+        im = Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).quantize(17)
+    else:
+        n = {"L": 1, "LA": 2, "RGB": 3, "RGBA": 4}[mode]
+        a = rng.integers(0, 256, size=(h, w, n), dtype=np.uint8)
+        im = Image.fromarray(a[..., 0] if n == 1 else a, mode)
+    path = tmp_path / f"t_{mode.replace(';', '')}.png"
+    if kw.get("interlace"):
+        pytest.importorskip("PIL")
+        # PIL cannot write Adam7; build one by hand from its scanlines
+        path = write_adam7(tmp_path / "adam7.png", np.asarray(im))
+    else:
+        im.save(path)
+    got, ch, req = load(img, path)
+    R = oracle.ref()
+    if R is not None:
+        wv, hv, c, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        p = R.ref_load_image(str(path).encode(), C.byref(wv), C.byref(hv), C.byref(c), C.byref(r))
+        assert p
+        ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(hv.value, wv.value, r.value)).copy()
+        R.ref_free(p)
+        assert (c.value, r.value) == (ch, req)
+        assert np.array_equal(ref, got)
+    else:
+        want = {1: "L", 2: "LA", 4: "RGBA"}[req]
+        ref = np.asarray(Image.open(path).convert(want)).reshape(h, w, req)
+        if mode != "I;16":
+            assert np.array_equal(ref, got)
+
+
+def write_adam7(path, rgb):
+    import struct
+    import zlib
+    h, w, _ = rgb.shape
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    raw = b""
+    for x0, y0, dx, dy in passes:
+        sub = rgb[y0::dy, x0::dx]
+        if sub.size:
+            for row in sub:
+                raw += b"\0" + row.tobytes()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) +
+                chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    return path
+
+
+@pytest.mark.parametrize("comp", [1, 2, 3, 4])
+def test_write_png_roundtrip(img, tmp_path, comp):
+    rng = np.random.default_rng(comp)
+    h, w = 41, 29
+    a = rng.integers(0, 256, size=(h, w, comp), dtype=np.uint8)
+    a[5:20, 3:25] = 77        # flat area: exercises the filter choice
+    path = tmp_path / f"w{comp}.png"
+    assert img.srx_image_write_png(str(path).encode(), w, h, comp, a.ctypes.data, 0) == 0
+    back = np.asarray(Image.open(path)).reshape(h, w, comp)
+    assert np.array_equal(back, a)
+    # with a row stride (a sub-rectangle of a wider image)
+    wide = np.zeros((h, w + 11, comp), np.uint8)
+    wide[:, :w] = a
+    assert img.srx_image_write_png(str(path).encode(), w, h, comp, wide.ctypes.data, (w + 11) * comp) == 0
+    assert np.array_equal(np.asarray(Image.open(path)).reshape(h, w, comp), a)
+
+
+def test_bad_files(img, tmp_path):
+    w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert img.srx_image_info(str(tmp_path / "none.png").encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(req)) == 1
+    p = tmp_path / "junk.png"
+    p.write_bytes(b"not a png at all, just bytes" * 4)
+    assert img.srx_image_info(str(p).encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(req)) == 1
+    good = open(os.path.join(ASSETS, "xiaoyao.png"), "rb").read()
+    p = tmp_path / "cut.png"
+    p.write_bytes(good[:3000])       # inside the single IDAT chunk
+    out = np.empty(91 * 91 * 4, np.uint8)
+    assert img.srx_image_load(str(p).encode(), out.ctypes.data, out.nbytes) == 1
