@@ -48,9 +48,10 @@ const TensorInfo kTensorInfo[SRX_T_COUNT] = {
 };
 
 // One kernel launch of the upscale sequence.
-enum StageKind { ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6, ST_HR_FUSED };
+enum StageKind { ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6, ST_HR_FUSED, ST_LR_FUSED };
 const char* const kStageNames[] = {"image_to_tensor", "conv1", "conv2", "conv3", "conv_up1",
-                                   "conv4", "conv5", "conv6_add_unorm", "conv4_conv5_conv6_add_unorm"};
+                                   "conv4", "conv5", "conv6_add_unorm", "conv4_conv5_conv6_add_unorm",
+                                   "pack_conv1_conv2_conv3_conv_up1"};
 
 }  // namespace
 
@@ -65,6 +66,8 @@ struct srx_ctx
     uint16_t* wpk[srx::kNumConvLayers] = {};
     float* bias[srx::kNumConvLayers] = {};
     uint16_t* wpk6Rows16 = nullptr;          // conv6 as 16x16x32 fragments (fused kernel)
+    uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
+    float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
 
     srx::Image input, output;
@@ -129,6 +132,20 @@ srx_status uploadWeights(srx_ctx* c)
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         c->wpk6Rows16 = static_cast<uint16_t*>(d);
     }
+    {
+        const std::vector<uint16_t> packed = PackConv1Rows8(c->folded.filter[0]);
+        void* d = nullptr;
+        if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
+        SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        c->wpk1Rows8 = static_cast<uint16_t*>(d);
+
+        std::vector<float> b;
+        for (int l : {3, 2, 1, 0})
+            for (uint16_t v : c->folded.bias[l]) b.push_back(ML::Float16ToFloat32(v));
+        if (const srx_status s = allocZero(c, &d, b.size() * 4)) return s;
+        SRX_HIP(hipMemcpy(d, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        c->biasLrFused = static_cast<float*>(d);
+    }
     return SRX_OK;
 }
 
@@ -139,7 +156,7 @@ srx_status allocTensors(srx_ctx* c)
     for (int id = 0; id < SRX_T_COUNT; ++id)
     {
         const TensorInfo& ti = kTensorInfo[id];
-        if (id >= SRX_T_CONV4 && !c->keep()) continue;   // never materialised by the fused kernel
+        if (id != SRX_T_CONV_UP1 && !c->keep()) continue;   // the fused kernels keep the rest in LDS
         const int w = int(c->width) * ti.scale, h = int(c->height) * ti.scale;
         const int pitch = roundUp(w, srx::kTileW) + 2 * ti.border + ti.slackRight;
         const int rows = roundUp(h, srx::kTileH) + 2 * ti.border;
@@ -203,7 +220,7 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
     {
         HrFusedLaunch hl;
         hl.a4 = c->tensor[SRX_T_CONV_UP1];
-        hl.x0 = frameOffset(c->tensor[SRX_T_INPUT], first);
+        hl.input = frameOffset(c->input, first);
         hl.wpk4 = c->wpk[4];
         hl.wpk5 = c->wpk[5];
         hl.wpk6 = c->wpk6Rows16;
@@ -214,6 +231,22 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
         hl.height2 = 2 * H;
         hl.batch = int(count);
         SRX_HIP(LaunchHrFused(hl, c->numCUs, s));
+        return SRX_OK;
+    }
+    if (stage == ST_LR_FUSED)
+    {
+        LrFusedLaunch ll;
+        ll.image = frameOffset(c->input, first);
+        ll.a4 = c->tensor[SRX_T_CONV_UP1];
+        ll.wpk1 = c->wpk1Rows8;
+        ll.wpk2 = c->wpk[1];
+        ll.wpk3 = c->wpk[2];
+        ll.wpkUp1 = c->wpk[3];
+        ll.bias = c->biasLrFused;
+        ll.width = W;
+        ll.height = H;
+        ll.batch = int(count);
+        SRX_HIP(LaunchLrFused(ll, c->numCUs, s));
         return SRX_OK;
     }
     const int l = int(stage) - int(ST_CONV1);
@@ -302,7 +335,7 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (c->keep())
         c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6};
     else
-        c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_HR_FUSED};
+        c->stages = {ST_LR_FUSED, ST_HR_FUSED};
     if (const srx_status s = uploadWeights(c)) return bail(s);
     if (const srx_status s = allocTensors(c)) return bail(s);
     {
@@ -396,6 +429,8 @@ srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
+    // the fused path converts the image inside its first kernel: nothing to launch here
+    if (c->stages[0] != ST_PACK) return SRX_OK;
     return launchStage(c, ST_PACK, 0, c->batch, static_cast<hipStream_t>(stream));
 }
 
@@ -406,7 +441,7 @@ srx_status srx_process(srx_ctx* c, void* stream)
     for (uint32_t first = 0; first < c->batch; first += c->chunk)
     {
         const uint32_t count = std::min(c->chunk, c->batch - first);
-        for (size_t i = 1; i < c->stages.size(); ++i)
+        for (size_t i = (c->stages[0] == ST_PACK ? 1 : 0); i < c->stages.size(); ++i)
             if (const srx_status s = launchStage(c, c->stages[i], first, count, static_cast<hipStream_t>(stream))) return s;
     }
     return SRX_OK;
@@ -529,7 +564,7 @@ srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
 {
     if (!validCtx(c) || i < 0 || i >= int32_t(c->stages.size())) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
     SRX_HIP(hipSetDevice(c->device));
-    const uint32_t count = (i == 0) ? c->batch : std::min(c->chunk, c->batch);
+    const uint32_t count = (c->stages[size_t(i)] == ST_PACK) ? c->batch : std::min(c->chunk, c->batch);
     return launchStage(c, c->stages[size_t(i)], 0, count, static_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,86 @@
+// Device-side helpers shared by the gfx950 kernel files (internal header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "srx_kernels.h"
+
+namespace srx {
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace dev {
+
+constexpr int kThreads = 256;
+
+struct TensorD
+{
+    f16* base;
+    int pitch;
+    long frame;
+};
+
+// Persistent, XCD-aware tile walk.  Workgroups are dealt round-robin over the 8
+// XCDs, so workgroups b and b+8 share an L2: give each XCD one contiguous range
+// of tiles (neighbouring tiles share their halo rows/columns through that L2).
+struct TileWalk
+{
+    int cur, end, step;
+    __device__ TileWalk(int numTiles)
+    {
+        const int g = gridDim.x, b = blockIdx.x;
+        if ((g & 7) == 0)
+        {
+            const int xcd = b & 7;
+            const long lo = (long(numTiles) * xcd) >> 3;
+            const long hi = (long(numTiles) * (xcd + 1)) >> 3;
+            cur = int(lo) + (b >> 3);
+            end = int(hi);
+            step = g >> 3;
+        }
+        else
+        {
+            cur = b;
+            end = numTiles;
+            step = g;
+        }
+    }
+    __device__ bool valid() const { return cur < end; }
+    __device__ void next() { cur += step; }
+};
+
+__device__ __forceinline__ f16x4 to_half4(float a, float b, float c, float d)
+{
+    f16x4 v;
+    v[0] = (f16)a; v[1] = (f16)b; v[2] = (f16)c; v[3] = (f16)d;
+    return v;
+}
+
+// float -> R8G8B8A8_UNORM channel: NaN -> 0, clamp, scale, +0.5, drop fraction.
+__device__ __forceinline__ unsigned unorm8(float v)
+{
+    v = (v == v) ? v : 0.0f;
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (unsigned)(v * 255.0f + 0.5f);
+}
+
+inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
+
+// Workgroups per launch: two per CU (or one when `perCU` is 1), a multiple of 8 so that the
+// XCD-aware walk applies, never more than there are work items.
+inline int gridFor(int numItems, int numCUs, int perCU = 2)
+{
+    int g = numCUs * perCU;
+    if (numItems < g) g = numItems;
+    if (g >= 8) g &= ~7;
+    return g < 1 ? 1 : g;
+}
+
+}  // namespace dev
+}  // namespace srx

@@ -57,7 +57,8 @@ struct ConvLaunch
 // a4 needs a border of at least 3 pixels and 64 pixels of slack to the right of the padded width.
 struct HrFusedLaunch
 {
-    Tensor a4, x0;
+    Tensor a4;
+    Image input;                     // RGBA8 input image: the residual term is NN2x of its tensor value
     const uint16_t *wpk4 = nullptr, *wpk5 = nullptr, *wpk6 = nullptr;   // wpk6: 16x16x32 fragments
     const float *bias4 = nullptr, *bias5 = nullptr;
     Image image;
@@ -65,6 +66,20 @@ struct HrFusedLaunch
     int batch = 1;
 };
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s);
+
+// image -> tensor + conv1 + conv2 + conv3 + conv_up1 in one kernel (rolling row windows in LDS):
+// reads the RGBA8 input image, writes conv_up1's output on the 2x grid.
+struct LrFusedLaunch
+{
+    Image image;                     // RGBA8 input
+    Tensor a4;                       // conv_up1 output
+    const uint16_t *wpk1 = nullptr;  // conv1 as 10 K-steps (PackConv1Rows8)
+    const uint16_t *wpk2 = nullptr, *wpk3 = nullptr, *wpkUp1 = nullptr;
+    const float* bias = nullptr;     // conv_up1[32] | conv3[64] | conv2[64] | conv1[32], fp32
+    int width = 0, height = 0;       // input size
+    int batch = 1;
+};
+hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);

@@ -13,30 +13,18 @@
 // Replaces the DirectML operators the reference dispatches in
 // SuperResolution::Process (Content/SuperResolution.cpp:73-103) and the
 // CSImageToTensor / PSTensorToImage shaders (Content/Shaders/*.hlsl).
-#include "srx_kernels.h"
+#include "srx_device.h"
 
 #include <cstdlib>
 
 namespace srx {
 
-typedef _Float16 f16;
-typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-typedef f16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace dev;
 
 namespace {
 
 constexpr int TW = kTileW;
 constexpr int TH = kTileH;
-constexpr int kThreads = 256;
-
-struct TensorD
-{
-    f16* base;
-    int pitch;
-    long frame;
-};
-
 struct ConvParams
 {
     TensorD in, out;
@@ -49,50 +37,6 @@ struct ConvParams
     uint8_t* image;
     long imagePitch, imageFrame;
 };
-
-// Persistent, XCD-aware tile walk.  Workgroups are dealt round-robin over the 8
-// XCDs, so workgroups b and b+8 share an L2: give each XCD one contiguous range
-// of tiles (neighbouring tiles share their halo rows/columns through that L2).
-struct TileWalk
-{
-    int cur, end, step;
-    __device__ TileWalk(int numTiles)
-    {
-        const int g = gridDim.x, b = blockIdx.x;
-        if ((g & 7) == 0)
-        {
-            const int xcd = b & 7;
-            const long lo = (long(numTiles) * xcd) >> 3;
-            const long hi = (long(numTiles) * (xcd + 1)) >> 3;
-            cur = int(lo) + (b >> 3);
-            end = int(hi);
-            step = g >> 3;
-        }
-        else
-        {
-            cur = b;
-            end = numTiles;
-            step = g;
-        }
-    }
-    __device__ bool valid() const { return cur < end; }
-    __device__ void next() { cur += step; }
-};
-
-__device__ __forceinline__ f16x4 to_half4(float a, float b, float c, float d)
-{
-    f16x4 v;
-    v[0] = (f16)a; v[1] = (f16)b; v[2] = (f16)c; v[3] = (f16)d;
-    return v;
-}
-
-// float -> R8G8B8A8_UNORM channel: NaN -> 0, clamp, scale, +0.5, drop fraction.
-__device__ __forceinline__ unsigned unorm8(float v)
-{
-    v = (v == v) ? v : 0.0f;
-    v = fminf(fmaxf(v, 0.0f), 1.0f);
-    return (unsigned)(v * 255.0f + 0.5f);
-}
 
 // ---------------------------------------------------------------------------
 // 3x3 convolutions
@@ -393,7 +337,9 @@ constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 67584
 
 struct HrParams
 {
-    TensorD a4, x0;
+    TensorD a4;
+    const uint8_t* input;            // RGBA8 input image
+    long inputPitch, inputFrame;
     const f16x8 *wpk4, *wpk5, *wpk6;
     const float *bias4, *bias5;
     uint8_t* image;
@@ -401,8 +347,6 @@ struct HrParams
     int width2, height2;
     int strips, segs, segRows, numItems;
 };
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
@@ -465,7 +409,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 
         // the residual term: NN2x(input) at this lane's conv6 pixel (clamped: masked lanes load a valid pixel)
         const int col6 = X0 + wave * 16 + p16;
-        const f16* x0f = p.x0.base + f * p.x0.frame + long(min(col6, p.width2 - 1) >> 1) * 4;
+        const uint8_t* x0f = p.input + f * p.inputFrame + long(min(col6, p.width2 - 1) >> 1) * 4;
 
         __syncthreads();
 #pragma unroll
@@ -482,8 +426,11 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         uint4 rowA = *reinterpret_cast<const uint4*>(ldSrc + Y0 * rowHalfs), rowB = rowA;
         uint4 rowAX = uint4{0, 0, 0, 0}, rowBX = rowAX;
         if (wave == 0) rowAX = *reinterpret_cast<const uint4*>(ldSrcX + Y0 * rowHalfs);
+        // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
         const auto loadX0 = [&](int r6) {
-            return *reinterpret_cast<const f16x4*>(x0f + long(min(max(r6, 0), p.height2 - 1) >> 1) * p.x0.pitch * 4);
+            const unsigned v = *reinterpret_cast<const unsigned*>(x0f + long(min(max(r6, 0), p.height2 - 1) >> 1) * p.inputPitch);
+            constexpr float k = 1.0f / 255.0f;
+            return to_half4(float(v & 0xff) * k, float((v >> 8) & 0xff) * k, float((v >> 16) & 0xff) * k, 0.0f);
         };
         f16x4 xinA = loadX0(Y0 - 6), xinB = xinA;
         __syncthreads();
@@ -593,16 +540,6 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     }
 }
 
-TensorD dev(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
-
-int gridFor(int numTiles, int numCUs)
-{
-    int g = numCUs * 2;
-    if (numTiles < g) g = numTiles;
-    if (g >= 8) g &= ~7;
-    return g < 1 ? 1 : g;
-}
-
 template <int CIN, int NT, int MODE>
 hipError_t launch3x3(const ConvParams& p, int numCUs, hipStream_t s)
 {
@@ -618,7 +555,7 @@ hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height
     const long total = long(width) * height * batch;
     const int blocks = int((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(PackKernel, dim3(blocks), dim3(256), 0, s, src.base, long(src.pitch), long(src.frame),
-                       dev(dst), width, height, total);
+                       toDevice(dst), width, height, total);
     return hipGetLastError();
 }
 
@@ -626,7 +563,7 @@ hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int heig
 {
     const long total = long(width) * height * batch;
     const int blocks = int((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(UnpackKernel, dim3(blocks), dim3(256), 0, s, dev(src), dst.base, long(dst.pitch),
+    hipLaunchKernelGGL(UnpackKernel, dim3(blocks), dim3(256), 0, s, toDevice(src), dst.base, long(dst.pitch),
                        long(dst.frame), width, height, total);
     return hipGetLastError();
 }
@@ -634,8 +571,10 @@ hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int heig
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
 {
     HrParams p{};
-    p.a4 = dev(l.a4);
-    p.x0 = dev(l.x0);
+    p.a4 = toDevice(l.a4);
+    p.input = l.input.base;
+    p.inputPitch = long(l.input.pitch);
+    p.inputFrame = long(l.input.frame);
     p.wpk4 = reinterpret_cast<const f16x8*>(l.wpk4);
     p.wpk5 = reinterpret_cast<const f16x8*>(l.wpk5);
     p.wpk6 = reinterpret_cast<const f16x8*>(l.wpk6);
@@ -676,8 +615,8 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
 hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s)
 {
     ConvParams p{};
-    p.in = dev(l.in);
-    p.out = dev(l.out);
+    p.in = toDevice(l.in);
+    p.out = toDevice(l.out);
     p.wpk = reinterpret_cast<const f16x8*>(l.wpk);
     p.bias = l.bias;
     p.width = l.width;
@@ -685,9 +624,9 @@ hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s)
     p.tilesX = (l.width + TW - 1) / TW;
     p.tilesY = (l.height + TH - 1) / TH;
     p.numTiles = p.tilesX * p.tilesY * l.batch;
-    p.x0 = dev(l.x0);
-    p.residual = dev(l.residual);
-    p.sum = dev(l.sum);
+    p.x0 = toDevice(l.x0);
+    p.residual = toDevice(l.residual);
+    p.sum = toDevice(l.sum);
     p.image = l.image.base;
     p.imagePitch = long(l.image.pitch);
     p.imageFrame = long(l.image.frame);

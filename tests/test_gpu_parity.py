@@ -203,4 +203,7 @@ def test_invalid_arguments():
     with S.SuperResolutionContext(16, 16) as ctx:
         assert L.srx_upload_rgba8(ctx._h, 3, None, 64, None) == 1
         assert L.srx_launch_stage(ctx._h, 99, None) == 1
-        assert ctx.stage_names()[0] == "image_to_tensor" and len(ctx.stage_names()) == L.srx_num_stages(ctx._h)
+        assert ctx.stage_names() == ["pack_conv1_conv2_conv3_conv_up1", "conv4_conv5_conv6_add_unorm"]
+        assert len(ctx.stage_names()) == L.srx_num_stages(ctx._h)
+    with S.SuperResolutionContext(16, 16, flags=S.FLAG_KEEP_TENSORS) as ctx:
+        assert ctx.stage_names()[0] == "image_to_tensor" and len(ctx.stage_names()) == 8
