@@ -25,7 +25,8 @@ OUT_MP = 4 * W * H / 1e6                       # 8.2944 output megapixels per fr
 # direct-form FLOPs (2 * MAC, unpadded channels, borders counted as full) per LR pixel
 FLOP_PER_LR_PIXEL = {"conv1": 4800, "conv2": 36864, "conv3": 73728, "conv_up1": 409600,
                      "conv4": 73728, "conv5": 73728, "conv6_add_unorm": 6912,
-                     "conv4_conv5_conv6_add_unorm": 73728 + 73728 + 6912}
+                     "conv4_conv5_conv6_add_unorm": 73728 + 73728 + 6912,
+                     "pack_conv1_conv2_conv3_conv_up1": 4800 + 36864 + 73728 + 409600}
 FLOP_PER_FRAME = 679360 * W * H                                     # 1408.72 GFLOP
 PEAK_FP16_DENSE = 2.5e15                       # MI355X dense fp16 MFMA, FLOP/s
 PEAK_HBM = 8.0e12

@@ -167,10 +167,11 @@ srx_status allocTensors(srx_ctx* c)
         c->tensorFrameBytes[id] = size_t(c->tensor[id].frame) * 2;
         if (id != SRX_T_INPUT) perFrame += c->tensorFrameBytes[id];
     }
-    // Frames resident per pass.  A large image fills the GPU on its own, and running all layers
-    // of one frame before the next keeps its activations warm in the 256 MiB Infinity Cache;
-    // small images are batched into one launch per layer.  SRX_WORKSPACE_MB overrides.
-    size_t budget = size_t(4) << 30;
+    // Frames resident per pass.  A large image fills the GPU on its own (its strips and row
+    // segments already make one work item per CU), so it runs one frame per pass and the
+    // workspace stays small; small images are batched into one launch per stage so that the
+    // launch still has work for every CU.  SRX_WORKSPACE_MB overrides.
+    size_t budget = size_t(256) << 20;
     if (const char* env = std::getenv("SRX_WORKSPACE_MB"))
         budget = std::max<size_t>(1, std::strtoull(env, nullptr, 10)) << 20;
     uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, budget / std::max<size_t>(perFrame, 1))));

@@ -70,6 +70,14 @@ __device__ __forceinline__ unsigned unorm8(float v)
     return (unsigned)(v * 255.0f + 0.5f);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, which would make every step of a rolling-window kernel wait for its global stores to be
+// acknowledged and for its prefetch loads to land; LDS writes are complete once lgkmcnt reaches 0.
+__device__ __forceinline__ void barrierLds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
 
 // Workgroups per launch: two per CU (or one when `perCU` is 1), a multiple of 8 so that the

@@ -367,6 +367,11 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         for (int s = 0; s < 18; ++s) wmain[s] = src[s * 64 + lane];
 #pragma unroll
         for (int s = 0; s < 9; ++s) w6[s] = p.wpk6[s * 64 + lane];
+        // make the loads land here, not behind vmcnt waits inside the step loop
+#pragma unroll
+        for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(wmain[s]));
+#pragma unroll
+        for (int s = 0; s < 9; ++s) asm volatile("" ::"v"(w6[s]));
     }
     float bias[16];
     {
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                 *reinterpret_cast<uint4*>(dst + ldOff) = park;
                 if (wave == 0) *reinterpret_cast<uint4*>(dst + ldOffX) = parkX;
             }
-            if (EXP != 5) __syncthreads();
+            if (EXP != 5) barrierLds();
         };
 
         // steps Y0-2 .. Y1+3, rounded up to an even count (a surplus step only touches ring rows

@@ -86,11 +86,12 @@ __device__ __forceinline__ void reluPack(const f32x16& acc, bool inside, f16x4 (
 
 // K-loop scheduling hint: keep `ahead` LDS reads in flight in front of the MFMAs that consume
 // them; `perRead` MFMAs follow every read.
+// The bias reads that seed the accumulators are LDS reads too and come first.
 template <int READS, int PER_READ>
 __device__ __forceinline__ void interleaveHint()
 {
-    constexpr int kAhead = 6;
-    __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+    constexpr int kAhead = 8;
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * PER_READ + kAhead, 0);
 #pragma unroll
     for (int k = 0; k < READS - kAhead; ++k)
     {
@@ -100,6 +101,7 @@ __device__ __forceinline__ void interleaveHint()
     __builtin_amdgcn_sched_group_barrier(0x008, kAhead * PER_READ, 0);
 }
 
+template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -119,6 +121,10 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         const int n = role == 3 ? 10 : 36;
 #pragma unroll
         for (int s = 0; s < 36; ++s) wreg[s] = src[(s < n ? s : 0) * 64 + lane];
+        // make the loads land here: a load still pending at the loop would put a vmcnt wait in front
+        // of every MFMA of every step, and those waits would also wait for the steps' global stores
+#pragma unroll
+        for (int s = 0; s < 36; ++s) asm volatile("" ::"v"(wreg[s]));
     }
 
     // pad columns of the rings are never written: they must hold finite values
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv_up1, phase `wave`, row t - 6 ----
                 const int ru = t - 6;
-                if (ru >= Y0 && ru < Y1)
+                if (ru >= Y0 && ru < Y1 && EXP != 2)
                 {
                     const int py = wave >> 1, pxp = wave & 1;
 #pragma unroll
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                                 d[4 * pair + k] = r[0];
                                 d[4 * pair + 2 + k] = r[1];
                             }
-                        if (i < kLrStrip && col < p.width)
+                        if (i < kLrStrip && col < p.width && EXP != 1)
                         {
                             f16* dst = p.a4.base + f * p.a4.frame +
                                        (long(2 * ru + py) * p.a4.pitch + (2 * col + pxp)) * 32 + h * 8;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv3, outputs 32 * (wave - 4) .., row t - 4 ----
                 const int r3 = t - 4;
-                if (r3 >= Y0 - 1 && r3 <= Y1)
+                if (r3 >= Y0 - 1 && r3 <= Y1 && EXP != 3)
                 {
                     const int nt = wave - 4;
 #pragma unroll
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv2, all 64 outputs, row t - 2 ----
                 const int r2 = t - 2;
-                if (r2 >= Y0 - 2 && r2 <= Y1 + 1)
+                if (r2 >= Y0 - 2 && r2 <= Y1 + 1 && EXP != 4)
                 {
 #pragma unroll
                     for (int tile = 0; tile < 2; ++tile)
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 const unsigned in0 = fetch(t + 3, lane);
                 const unsigned in1 = lane < 6 ? fetch(t + 3, 64 + lane) : 0u;
                 const int r1 = t;
-                if (r1 <= Y1 + 2)
+                if (r1 <= Y1 + 2 && EXP != 4)
                 {
 #pragma unroll
                     for (int tile = 0; tile < 3; ++tile)
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 park(t + 3, lane, in0);
                 if (lane < 6) park(t + 3, 64 + lane, in1);
             }
-            __syncthreads();
+            if (EXP != 5) barrierLds();
         }
     }
 }
@@ -378,12 +384,20 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
     if (!attr[device])
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(LrFusedKernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLrSmem);
-        if (e != hipSuccess) return e;
         attr[device] = true;
     }
-    hipLaunchKernelGGL(LrFusedKernel, dim3(gridFor(p.numItems, numCUs, 1)), dim3(kLrThreads), kLrSmem, s, p);
+    const char* env = getenv("SRX_EXP_LR");
+    const int exp = env ? atoi(env) : 0;
+    const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);
+    switch (exp)
+    {
+    case 1: hipLaunchKernelGGL(LrFusedKernel<1>, grid, block, kLrSmem, s, p); break;
+    case 2: hipLaunchKernelGGL(LrFusedKernel<2>, grid, block, kLrSmem, s, p); break;
+    case 3: hipLaunchKernelGGL(LrFusedKernel<3>, grid, block, kLrSmem, s, p); break;
+    case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
+    case 5: hipLaunchKernelGGL(LrFusedKernel<5>, grid, block, kLrSmem, s, p); break;
+    default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
+    }
     return hipGetLastError();
 }
 
