@@ -105,10 +105,8 @@ def main():
         ctx.upscale(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from superresolution_amd.sharding import max_over_ranks
+    elapsed = max_over_ranks(elapsed)          # the job takes as long as its slowest rank
     barrier()
 
     # per-kernel durations, HIP events on the launch stream (one launch covers the frames of

@@ -162,6 +162,18 @@ def test_spatial_tiles_with_halo_are_bit_identical():
         assert np.array_equal(crop, full[2 * y0:2 * y1, 2 * x0:2 * x1])
 
 
+def test_tiled_helper_reproduces_untiled_run():
+    from superresolution_amd import sharding
+    rgba = synthetic_rgba(150, 101, 77)
+    with S.SuperResolutionContext(150, 101) as ctx:
+        full = ctx.run(rgba)
+    assert np.array_equal(sharding.upscale_tiled(rgba, 3, 2), full)
+    # two "ranks" each paste their own tiles into the same canvas
+    out = sharding.upscale_tiled(rgba, 2, 4, rank=0, world=2)
+    out = sharding.upscale_tiled(rgba, 2, 4, rank=1, world=2, out=out)
+    assert np.array_equal(out, full)
+
+
 def test_full_hd_properties():
     """1920x1080 -> 3840x2160 (the benchmark size), checked through size-independent properties:
     determinism, agreement of an interior crop with the same crop run as its own image (with
