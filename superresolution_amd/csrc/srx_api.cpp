@@ -292,8 +292,10 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (!out) return fail(SRX_ERR_INVALID, "srx_create: out is NULL");
     *out = nullptr;
     if (!weights_path) return fail(SRX_ERR_INVALID, "srx_create: weights_path is NULL");
-    if (in_w == 0 || in_h == 0 || batch == 0 || in_w > 16384 || in_h > 16384)
-        return fail(SRX_ERR_INVALID, "srx_create: image size must be 1..16384 and batch >= 1");
+    // one output frame (2W x 2H x 4 bytes) must stay addressable with a 32-bit offset
+    if (in_w == 0 || in_h == 0 || batch == 0 || in_w > 16384 || in_h > 16384 ||
+        uint64_t(in_w) * in_h > (uint64_t(1) << 27))
+        return fail(SRX_ERR_INVALID, "srx_create: image size must be 1..16384 per side, at most 2^27 pixels, and batch >= 1");
 
     srx::ML::WeightMapType weights;
     if (!srx::LoadWeights(weights_path, weights, (flags & SRX_FLAG_VERBOSE_WEIGHTS) != 0))

@@ -15,7 +15,9 @@
 // CSImageToTensor / PSTensorToImage shaders (Content/Shaders/*.hlsl).
 #include "srx_device.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace srx {
 
@@ -346,7 +348,17 @@ struct HrParams
     long imagePitch, imageFrame;
     int width2, height2;
     int strips, segs, segRows, numItems;
+    unsigned long long* stamps;      // diagnostic build only (EXP == 8)
 };
+
+__device__ __forceinline__ unsigned long long stampNow()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
@@ -380,6 +392,13 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         for (int r = 0; r < 16; ++r) bias[r] = src[(r & 3) + 8 * (r >> 2) + 4 * h];
     }
 
+    // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe.  Left alone
+    // they fall into lockstep (both in their MFMA phase, then both in their epilogue, pipe idle).
+    // A static priority for every other workgroup lets one wave run its MFMA phase unhindered
+    // while the other does its epilogue, and vice versa.  Workgroups b and b + #CUs usually share
+    // a CU; if they do not, nothing is lost.
+    if (EXP != 6 && ((blockIdx.x / (gridDim.x >> 1 ? gridDim.x >> 1 : 1)) & 1)) __builtin_amdgcn_s_setprio(1);
+
     // never-written pad columns of the rings must hold finite values
     for (int i = tid * 16; i < kHrSmem; i += kThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
 
@@ -387,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int outRing = L ? kHrA6 : kHrA5;
     const int outStride = L ? kHrStride6 : kHrStride32;
     const int outRow = L ? kHrRow6 : kHrRow32;
-    const int rowLag = L ? 2 : 0;
+    const int rowLag = L ? 3 : 0;
     const int colOff = (L ? -1 : -2) + ti * 32 + px;
     const int inLane = (ti * 32 + px) * kHrStride32 + h * 16;
     const int in6Lane = (wave * 16 + p16) * kHrStride6 + q * 16;
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int ldPixX = min(64 + (lane >> 2), kHrRowPix - 1);
     const int ldOffX = ldPixX * kHrStride32 + (lane & 3) * 16;
 
+    unsigned long long stampSum[4] = {0, 0, 0, 0};
     const int perFrame = p.strips * p.segs;
     for (TileWalk tw(p.numItems); tw.valid(); tw.next())
     {
@@ -411,6 +431,9 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         const f16* ldSrc = a4f + (tid >> 2) * 32 + (tid & 3) * 8;
         const f16* ldSrcX = a4f + ldPixX * 32 + (lane & 3) * 8;
         const long rowHalfs = long(p.a4.pitch) * 32;
+
+        const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.image + f * p.imageFrame, 0, int(p.imageFrame), 0x00020000);
 
         // the residual term: NN2x(input) at this lane's conv6 pixel (clamped: masked lanes load a valid pixel)
         const int col6 = X0 + wave * 16 + p16;
@@ -430,30 +453,75 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         // step to land; the loop is unrolled by two so the sets never need copying.
         uint4 rowA = *reinterpret_cast<const uint4*>(ldSrc + Y0 * rowHalfs), rowB = rowA;
         uint4 rowAX = uint4{0, 0, 0, 0}, rowBX = rowAX;
-        if (wave == 0) rowAX = *reinterpret_cast<const uint4*>(ldSrcX + Y0 * rowHalfs);
+        rowAX = *reinterpret_cast<const uint4*>(ldSrcX + Y0 * rowHalfs);
         // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
         const auto loadX0 = [&](int r6) {
             const unsigned v = *reinterpret_cast<const unsigned*>(x0f + long(min(max(r6, 0), p.height2 - 1) >> 1) * p.inputPitch);
             constexpr float k = 1.0f / 255.0f;
             return to_half4(float(v & 0xff) * k, float((v >> 8) & 0xff) * k, float((v >> 16) & 0xff) * k, 0.0f);
         };
-        f16x4 xinA = loadX0(Y0 - 6), xinB = xinA;
+        f16x4 xinA = loadX0(Y0 - 8), xinB = xinA;
+        // Accumulators are finished ONE STEP LATER: step t converts / stores what step t-1
+        // accumulated while its own MFMAs run, so the epilogue's VALU work hides behind the matrix
+        // pipe instead of following it.  Two accumulator sets alternate (loop unrolled by two).
+        f32x16 accA, accB;
+        f32x4 acc6A = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc6B = acc6A;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.0f;
         __syncthreads();
 
         const auto step = [&](const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
-                              const f16x4& xin, f16x4& xinNext) {
+                              const f16x4& xin, f16x4& xinNext, const f32x16& accPrev, f32x16& acc,
+                              const f32x4& acc6Prev, f32x4& acc6) {
+            unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (EXP == 8) s0 = stampNow();
             const long nrow = min(t + 3, Y1 + 2);
             if (EXP != 4)
             {
+                // every wave fetches (and later parks) the 8 extra chunks: identical bytes to identical
+                // LDS addresses, and the step stays one basic block
                 load = *reinterpret_cast<const uint4*>(ldSrc + nrow * rowHalfs);
-                if (wave == 0) loadX = *reinterpret_cast<const uint4*>(ldSrcX + nrow * rowHalfs);
+                loadX = *reinterpret_cast<const uint4*>(ldSrcX + nrow * rowHalfs);
             }
-            const int r6 = t - 4;
-            if (EXP != 1 && EXP != 2) xinNext = loadX0(r6 + 1);
-
-            // conv4 (row t) or conv5 (row t - 2)
+            // rows: conv4 accumulates row t, conv5 row t-3, conv6 row t-6; the rows finished in this
+            // step are one less each
             const int rc = t - rowLag;
-            f32x16 acc;
+            const int r6 = t - 6;
+            if (EXP != 1 && EXP != 2) xinNext = loadX0(r6);
+
+            // ---- finish step t-1: conv4 / conv5 row rc-1 -> ring (ReLU, zero outside the image, fp16)
+            if (EXP == 3) asm volatile("" ::"v"(accPrev));
+            else
+            {
+                const int col = X0 + colOff;
+                const bool inside = (int(rc - 1 >= 0) & int(rc - 1 < p.height2) & int(col >= 0) & int(col < p.width2)) != 0;
+                char* dst = smem + outRing + ((rc - 1) & 3) * outRow + outLane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                {
+                    f16x4 v = to_half4(accPrev[4 * g], accPrev[4 * g + 1], accPrev[4 * g + 2], accPrev[4 * g + 3]);
+                    v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
+                    if (!inside) v = f16x4{0, 0, 0, 0};
+                    *reinterpret_cast<f16x4*>(dst + g * 16) = v;
+                }
+            }
+            // ---- finish step t-1: conv6 row r6-1.  D rows 0..2 (lanes 0..15) are R, G, B of pixel
+            // wave*16 + p16.  Branch-free: lanes that own no output pixel store through the buffer
+            // descriptor at an offset beyond its range, which the hardware drops.
+            if (EXP != 2)
+            {
+                const int ro = r6 - 1;
+                const f16x4 res = to_half4(acc6Prev[0], acc6Prev[1], acc6Prev[2], 0.0f);
+                const f16x4 sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
+                                           (float)res[2] + (float)xin[2], 0.0f);
+                const unsigned rgba = unorm8((float)sum[0]) | (unorm8((float)sum[1]) << 8) |
+                                      (unorm8((float)sum[2]) << 16) | 0xff000000u;
+                const bool owns = (int(q == 0) & int(wave * 16 + p16 < kHrStrip) & int(col6 < p.width2) & int(ro >= Y0) & int(ro < Y1)) != 0;
+                const unsigned off = owns ? unsigned(ro) * unsigned(p.imagePitch) + unsigned(col6) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b32(rgba, imageRsrc, int(off), 0, 0);
+            }
+
+            // ---- conv4 (row t) or conv5 (row t - 3)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bias[r];
 #pragma unroll
@@ -470,8 +538,8 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                     }
             }
 
-            // conv6 (row t - 4), 16 pixels per wave
-            f32x4 acc6 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // ---- conv6 (row t - 6), 16 pixels per wave
+            acc6 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (EXP != 2)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -486,63 +554,49 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                 }
             if (EXP != 6)
             {
-                // keep several LDS reads in flight ahead of the MFMA that consumes them
-                constexpr int kAhead = EXP == 7 ? 10 : 6;
+                // LDS reads run kAhead in front of the MFMAs that consume them, and the previous
+                // step's epilogue (VALU) is spread over the gaps between MFMAs
+                constexpr int kAhead = 6;
+                constexpr int kValuPerGap = EXP == 7 ? 0 : 3;
                 __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
-                for (int k = 0; k < 27 - kAhead; ++k)
+                for (int k = 0; k < 27; ++k)
                 {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
-            }
-
-            // epilogue of conv4 / conv5: bias is in, ReLU, zero outside the image, fp16, into the ring
-            if (EXP == 3) asm volatile("" ::"v"(acc));
-            else
-            {
-                const int col = X0 + colOff;
-                const bool inside = rc >= 0 && rc < p.height2 && col >= 0 && col < p.width2;
-                char* dst = smem + outRing + (rc & 3) * outRow + outLane;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                {
-                    f16x4 v = to_half4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-                    v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
-                    if (!inside) v = f16x4{0, 0, 0, 0};
-                    *reinterpret_cast<f16x4*>(dst + g * 16) = v;
+                    if (k < 27 - kAhead) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (kValuPerGap) __builtin_amdgcn_sched_group_barrier(0x002, kValuPerGap, 0);
                 }
             }
-
-            // epilogue of conv6: D rows 0..2 (lanes 0..15) are R, G, B of pixel wave*16 + p16
-            if (EXP != 2 && q == 0 && wave * 16 + p16 < kHrStrip && col6 < p.width2 && r6 >= Y0 && r6 < Y1)
-            {
-                const f16x4 res = to_half4(acc6[0], acc6[1], acc6[2], 0.0f);
-                const f16x4 sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
-                                           (float)res[2] + (float)xin[2], 0.0f);
-                const unsigned rgba = unorm8((float)sum[0]) | (unorm8((float)sum[1]) << 8) |
-                                      (unorm8((float)sum[2]) << 16) | 0xff000000u;
-                *reinterpret_cast<unsigned*>(p.image + f * p.imageFrame + long(r6) * p.imagePitch + col6 * 4) = rgba;
-            }
+            if (EXP == 8) s1 = stampNow();
 
             // park row t+2
             {
                 char* dst = smem + kHrA4 + ((t + 2) & 3) * kHrRow32;
                 *reinterpret_cast<uint4*>(dst + ldOff) = park;
-                if (wave == 0) *reinterpret_cast<uint4*>(dst + ldOffX) = parkX;
+                *reinterpret_cast<uint4*>(dst + ldOffX) = parkX;
             }
+            if (EXP == 8) s2 = stampNow();
             if (EXP != 5) barrierLds();
+            if (EXP == 8)
+            {
+                s3 = stampNow();
+                stampSum[0] += s1 - s0;
+                stampSum[1] += s2 - s1;
+                stampSum[2] += s3 - s2;
+                stampSum[3] += 1;
+            }
         };
 
-        // steps Y0-2 .. Y1+3, rounded up to an even count (a surplus step only touches ring rows
+        // steps Y0-2 .. Y1+6, rounded up to an even count (a surplus step only touches ring rows
         // nothing reads and stores nothing)
-        for (int t = Y0 - 2; t <= Y1 + 3; t += 2)
+        for (int t = Y0 - 2; t <= Y1 + 6; t += 2)
         {
-            step(t, rowA, rowAX, rowB, rowBX, xinA, xinB);
-            step(t + 1, rowB, rowBX, rowA, rowAX, xinB, xinA);
+            step(t, rowA, rowAX, rowB, rowBX, xinA, xinB, accA, accB, acc6A, acc6B);
+            step(t + 1, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
         }
     }
+    if (EXP == 8 && p.stamps && lane == 0)
+        for (int k = 0; k < 4; ++k) p.stamps[(blockIdx.x * 4 + wave) * 4 + k] = stampSum[k];
 }
 
 template <int CIN, int NT, int MODE>
@@ -602,7 +656,8 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     if (p.numItems <= 0) return hipErrorInvalidValue;
     const char* env = getenv("SRX_EXP");
     const int exp = env ? atoi(env) : 0;
-    const dim3 grid(gridFor(p.numItems, numCUs)), block(kThreads);
+    const char* perCuEnv = getenv("SRX_HR_PER_CU");
+    const dim3 grid(gridFor(p.numItems, numCUs, perCuEnv ? atoi(perCuEnv) : 2)), block(kThreads);
     switch (exp)
     {
     case 1: hipLaunchKernelGGL(HrFusedKernel<1>, grid, block, kHrSmem, s, p); break;
@@ -612,6 +667,24 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     case 5: hipLaunchKernelGGL(HrFusedKernel<5>, grid, block, kHrSmem, s, p); break;
     case 6: hipLaunchKernelGGL(HrFusedKernel<6>, grid, block, kHrSmem, s, p); break;
     case 7: hipLaunchKernelGGL(HrFusedKernel<7>, grid, block, kHrSmem, s, p); break;
+    case 8:
+    {
+        // diagnostic: where a step spends its cycles (sums per wave of issue / epilogue / barrier time)
+        static unsigned long long* d = nullptr;
+        const size_t n = size_t(grid.x) * 16;
+        if (!d && hipMalloc(&d, 512 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        p.stamps = d;
+        hipLaunchKernelGGL(HrFusedKernel<8>, grid, block, kHrSmem, s, p);
+        std::vector<unsigned long long> h(n);
+        if (hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < n; ++i) sum[i & 3] += double(h[i]);
+        static int once = 0;
+        if (once++ == 3)
+            fprintf(stderr, "HR stamps per step (cycles): mfma-section %.0f  epilogue %.0f  barrier %.0f  (steps %.0f per wave)\n",
+                    sum[0] / sum[3], sum[1] / sum[3], sum[2] / sum[3], sum[3] / (n / 4));
+        break;
+    }
     default: hipLaunchKernelGGL(HrFusedKernel<0>, grid, block, kHrSmem, s, p); break;
     }
     return hipGetLastError();

@@ -127,6 +127,11 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         for (int s = 0; s < 36; ++s) asm volatile("" ::"v"(wreg[s]));
     }
 
+    // Waves w and w + 4 share a SIMD and its MFMA pipe and have the same amount of work per step;
+    // left alone they run in lockstep (both in MFMAs, then both in epilogues with the pipe idle).
+    // A static priority for one of them staggers the two.
+    if (EXP != 6 && role == 0) __builtin_amdgcn_s_setprio(1);
+
     // pad columns of the rings are never written: they must hold finite values
     for (int i = tid * 16; i < kLrSmem; i += kLrThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
     __syncthreads();
@@ -396,6 +401,7 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     case 3: hipLaunchKernelGGL(LrFusedKernel<3>, grid, block, kLrSmem, s, p); break;
     case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
     case 5: hipLaunchKernelGGL(LrFusedKernel<5>, grid, block, kLrSmem, s, p); break;
+    case 6: hipLaunchKernelGGL(LrFusedKernel<6>, grid, block, kLrSmem, s, p); break;
     default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
     }
     return hipGetLastError();
