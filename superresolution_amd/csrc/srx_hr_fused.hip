@@ -1,0 +1,426 @@
+// gfx950 kernel: conv4 -> conv5 -> conv6 -> + NN2x(input) -> UNORM8, fused.
+//
+// A workgroup (4 waves, 66 KB LDS, two workgroups per CU) walks a strip of
+// kHrStrip output columns downwards one row per step, keeping rolling windows of
+// conv_up1's output and of the two intermediate activations in LDS rings, so
+// neither intermediate touches HBM and no row is computed twice vertically.  One
+// LDS barrier separates steps.  Wave w accumulates, per step, its 32-pixel half
+// (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) with 18
+// v_mfma_f32_32x32x16_f16, and its 16-pixel quarter of one row of conv6 with 9
+// v_mfma_f32_16x16x32_f16 (3 outputs padded to 16): every wave issues the same work.
+//
+// Software pipeline: what step t accumulates is converted and stored by step t+1,
+// a few VALU instructions in each gap between that step's MFMAs, so the epilogue
+// runs under the matrix pipe instead of after it.  Rows per step t:
+//     accumulate: conv4 row t      conv5 row t-3     conv6 row t-6
+//     finish:     conv4 row t-1    conv5 row t-4     conv6 row t-7
+// The loop is unrolled by four so every ring slot is a compile-time constant.
+//
+// Column bookkeeping for a strip whose first output column is X0:
+//   conv6 pixel i   = column X0 + i      (60 of 64 kept), reads a6 index i..i+2
+//   a6 ring index i = column X0 - 1 + i = conv5 pixel i, which reads a5 index i..i+2
+//   a5 ring index i = column X0 - 2 + i = conv4 pixel i, which reads a4 index i..i+2
+//   a4 ring index i = column X0 - 3 + i   (66 pixels loaded per row)
+// Activations outside the true image are written as zeros: that is the zero
+// padding each of the reference's convolutions applies to its own input
+// (Content/SuperResolution.cpp:245-268 via ML::Util::CreateConvolutionLayer); the
+// residual add and the conversion are ELEMENT_WISE_ADD (Content/SuperResolution.cpp:700-702)
+// and PSTensorToImage.hlsl:14-35 + the R8G8B8A8_UNORM render target.
+#include "srx_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace srx {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kHrStrip = 60;
+constexpr int kHrRowPix = 66;
+constexpr int kHrStride32 = 80;                       // a4 / a5 pixel stride (odd number of 16-B slots)
+constexpr int kHrStride6 = 96;                        // a6 pixel stride: conflict-free for the 16x16x32 reads
+constexpr int kHrRow32 = kHrRowPix * kHrStride32;     // 5280
+constexpr int kHrRow6 = kHrRowPix * kHrStride6;       // 6336
+constexpr int kHrA4 = 0;
+constexpr int kHrA5 = 4 * kHrRow32;
+constexpr int kHrA6 = 8 * kHrRow32;
+constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 67584
+
+struct HrParams
+{
+    TensorD a4;
+    const uint8_t* input;            // RGBA8 input image
+    long inputPitch, inputFrame;
+    const f16x8 *wpk4, *wpk5, *wpk6;
+    const float *bias4, *bias5;
+    uint8_t* image;
+    long imagePitch, imageFrame;
+    int width2, height2;
+    int strips, segs, segRows, numItems;
+    unsigned long long* stamps;      // diagnostic build only (EXP & 2048)
+};
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+// EXP: 0 = as designed; 1 = no scheduling pins (compiler order); 2 = no static priority.
+template <int EXP>
+__global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int px = lane & 31, h = lane >> 5;      // 32x32x16 fragment coordinates
+    const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates
+    const int L = wave >> 1, ti = wave & 1;
+
+    unsigned long long c0 = 0, r0 = 0;
+    if constexpr ((EXP & 2048) != 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f16x8 wmain[18], w6[9];
+    {
+        const f16x8* src = L ? p.wpk5 : p.wpk4;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) wmain[s] = src[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) w6[s] = p.wpk6[s * 64 + lane];
+        // make the loads land here, not behind vmcnt waits inside the step loop
+#pragma unroll
+        for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(wmain[s]));
+#pragma unroll
+        for (int s = 0; s < 9; ++s) asm volatile("" ::"v"(w6[s]));
+    }
+    f32x16 bias;
+    {
+        const float* src = L ? p.bias5 : p.bias4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = src[(r & 3) + 8 * (r >> 2) + 4 * h];
+    }
+
+    // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe; a static
+    // priority for every other workgroup keeps the two from settling into lockstep.  Workgroups b
+    // and b + #CUs usually share a CU; if they do not, nothing is lost.
+    if ((EXP & 2) == 0 && ((blockIdx.x / (gridDim.x >> 1 ? gridDim.x >> 1 : 1)) & 1)) __builtin_amdgcn_s_setprio(1);
+
+    // never-written pad columns of the rings must hold finite values
+    for (int i = tid * 16; i < kHrSmem; i += kThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
+
+    // Ring slots.  Row r of an item lives in slot (r - t0) & 3, t0 = the item's first step.  With
+    // the loop unrolled by four the phase PH = (t - t0) & 3 is a compile-time constant, and so is
+    // every slot except for the layer-dependent lag (conv5 trails conv4 by 3 rows = 1 slot): that
+    // one rotation is folded into these tables, indexed by a compile-time (PH + offset) & 3.
+    const int rot = L ? 1 : 0;                     // (-lag) & 3
+    const int inRing = L ? kHrA5 : kHrA4;
+    const int outRing = L ? kHrA6 : kHrA5;
+    const int outStride = L ? kHrStride6 : kHrStride32;
+    const int outRow = L ? kHrRow6 : kHrRow32;
+    int inSlot[4], outSlot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        inSlot[k] = inRing + ((k + rot) & 3) * kHrRow32;
+        outSlot[k] = outRing + ((k + rot) & 3) * outRow;
+    }
+    const int lag = L ? 3 : 0;
+    const int colOff = (L ? -1 : -2) + ti * 32 + px;
+    const int inLane = (ti * 32 + px) * kHrStride32 + h * 16;
+    const int in6Lane = kHrA6 + (wave * 16 + p16) * kHrStride6 + q * 16;
+    const int outLane = (ti * 32 + px) * outStride + h * 8;
+    // row loader: 66 pixels x 4 chunks of 16 B; thread t takes chunk t, and every wave also
+    // takes the last 8 chunks (identical bytes to identical addresses: keeps the step branch-free)
+    const int ldOff = kHrA4 + (tid >> 2) * kHrStride32 + (tid & 3) * 16;
+    const int ldPixX = min(64 + (lane >> 2), kHrRowPix - 1);
+    const int ldOffX = kHrA4 + ldPixX * kHrStride32 + (lane & 3) * 16;
+
+    const int perFrame = p.strips * p.segs;
+    for (TileWalk tw(p.numItems); tw.valid(); tw.next())
+    {
+        const int f = tw.cur / perFrame;
+        const int rem = tw.cur - f * perFrame;
+        const int seg = rem / p.strips;
+        const int X0 = (rem - seg * p.strips) * kHrStrip;
+        const int Y0 = seg * p.segRows;
+        const int Y1 = min(p.height2, Y0 + p.segRows);
+        const int t0 = Y0 - 2;
+
+        const long rowBytes = long(p.a4.pitch) * 64;
+        const char* a4f = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + (long(X0) - 3) * 32);
+        // per-lane pointers to this lane's chunk of the NEXT row to fetch
+        const char* ldPtr = a4f + (tid >> 2) * 64 + (tid & 3) * 16 + (Y0 - 3) * rowBytes;
+        const char* ldPtrX = a4f + ldPixX * 64 + (lane & 3) * 16 + (Y0 - 3) * rowBytes;
+
+        const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.image + f * p.imageFrame, 0, int(p.imageFrame), 0x00020000);
+
+        // conv6: this lane's output column, whether it owns an output pixel, its byte offset in a row
+        const int col6 = X0 + wave * 16 + p16;
+        const bool laneOwns = q == 0 && wave * 16 + p16 < kHrStrip && col6 < p.width2;
+        const unsigned col6Bytes = unsigned(col6) * 4u;
+        // the residual term: NN2x(input) at this lane's conv6 pixel (clamped: masked lanes load a valid pixel)
+        const uint8_t* x0f = p.input + f * p.inputFrame + long(min(col6, p.width2 - 1) >> 1) * 4;
+        // conv4 / conv5: is this lane's column inside the image?
+        const bool colInside = X0 + colOff >= 0 && X0 + colOff < p.width2;
+
+        __syncthreads();
+        // rows Y0-3 .. Y0-1 go straight to LDS (slots of rows t0-1, t0, t0+1), row Y0 stays in flight
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+        {
+            const int slot = (rr - 1) & 3;       // row t0 - 1 + rr
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOff) = *reinterpret_cast<const uint4*>(ldPtr);
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOffX) = *reinterpret_cast<const uint4*>(ldPtrX);
+            ldPtr += rowBytes;
+            ldPtrX += rowBytes;
+        }
+        // Rows in flight in registers: step t issues the load of row t+3 into one register set and
+        // parks the other (row t+2, loaded during step t-1), so a load has a whole step to land.
+        uint4 rowA = *reinterpret_cast<const uint4*>(ldPtr), rowB = rowA;
+        uint4 rowAX = *reinterpret_cast<const uint4*>(ldPtrX), rowBX = rowAX;
+        ldPtr += rowBytes;
+        ldPtrX += rowBytes;
+        // the residual term is fetched one step early and stays raw until the step that uses it, so its
+        // latency never sits in front of the MFMAs
+        const auto loadX0 = [&](int row2x) {
+            return *reinterpret_cast<const unsigned*>(x0f + long(min(max(row2x, 0), p.height2 - 1) >> 1) * p.inputPitch);
+        };
+        // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
+        const auto toTensor = [](unsigned v) {
+            constexpr float k = 1.0f / 255.0f;
+            return to_half4(float(v & 0xff) * k, float((v >> 8) & 0xff) * k, float((v >> 16) & 0xff) * k, 0.0f);
+        };
+        unsigned xinA = loadX0(t0 - 7), xinB = xinA;
+        f32x16 accA, accB;
+        f32x4 acc6A = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc6B = acc6A;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.0f;
+        __syncthreads();
+
+        // One step.  PH = (t - t0) & 3.
+        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
+                              const unsigned& xinRaw, unsigned& xinNext, const f32x16& accPrev, f32x16& acc,
+                              const f32x4& acc6Prev, f32x4& acc6) {
+            constexpr int PH = decltype(phase)::value;
+            constexpr int kAhead = ((EXP >> 8) & 3) == 0 ? 6 : ((EXP >> 8) & 3) == 1 ? 3 : ((EXP >> 8) & 3) == 2 ? 10 : 14;
+            // ---- global loads: row t+3 (last needed row is Y1+2: stop advancing there) and the
+            // residual term of the row conv6 finishes NEXT step
+            if ((EXP & 32) == 0)
+            {
+                load = *reinterpret_cast<const uint4*>(ldPtr);
+                loadX = *reinterpret_cast<const uint4*>(ldPtrX);
+            }
+            const long adv = (t + 3 < Y1 + 2) ? rowBytes : 0;
+            ldPtr += adv;
+            ldPtrX += adv;
+            xinNext = loadX0(t - 6);
+
+            // ---- row bookkeeping of what this step finishes
+            const int rowDone = t - 1 - lag;                         // conv4 / conv5 row being finished
+            const bool rowInside = rowDone >= 0 && rowDone < p.height2;
+            const bool inside = rowInside & colInside;
+            const int ro = t - 7;                                    // conv6 row being finished
+            const bool owns = laneOwns & (ro >= Y0) & (ro < Y1);
+            const unsigned outOff = owns ? unsigned(ro) * unsigned(p.imagePitch) + col6Bytes : 0xffffffffu;
+
+            // ---- LDS addresses of this step
+            const char* in0 = smem + inSlot[(PH + 3) & 3] + inLane;  // rows rc-1, rc, rc+1 of the input ring
+            const char* in1 = smem + inSlot[PH] + inLane;
+            const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;
+            const char* c60 = smem + ((PH + 1) & 3) * kHrRow6 + in6Lane;   // rows t-7, t-6, t-5 of a6
+            const char* c61 = smem + ((PH + 2) & 3) * kHrRow6 + in6Lane;
+            const char* c62 = smem + ((PH + 3) & 3) * kHrRow6 + in6Lane;
+            char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;   // row rc-1 of the output ring
+
+            const auto readFrag = [&](auto kk) -> f16x8 {
+                constexpr int K = decltype(kk)::value;
+                if constexpr ((EXP & 4) != 0) { f16x8 x = wmain[K % 18]; asm volatile("" : "+v"(x)); return x; }
+                else if constexpr (K < 18)
+                {
+                    constexpr int i = K / 6, j = (K % 6) / 2, cc = K % 2;
+                    const char* b = i == 0 ? in0 : (i == 1 ? in1 : in2);
+                    return *reinterpret_cast<const f16x8*>(b + j * kHrStride32 + cc * 32);
+                }
+                else
+                {
+                    constexpr int i = (K - 18) / 3, j = (K - 18) % 3;
+                    const char* b = i == 0 ? c60 : (i == 1 ? c61 : c62);
+                    return *reinterpret_cast<const f16x8*>(b + j * kHrStride6);
+                }
+            };
+
+            // epilogue state carried between the pieces below
+            f16x4 v0 = f16x4{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, res = v0, sum = v0, xin = v0;
+            unsigned c0 = 0, c1 = 0, c2 = 0;
+            const auto reluHalf4 = [&](int g) {
+                f16x4 v = to_half4(accPrev[4 * g], accPrev[4 * g + 1], accPrev[4 * g + 2], accPrev[4 * g + 3]);
+                v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
+                return inside ? v : f16x4{0, 0, 0, 0};
+            };
+            // Piece K of the previous step's epilogue, issued in the gap after MFMA K.
+            const auto piece = [&](auto kk) {
+                constexpr int K = decltype(kk)::value;
+                if constexpr (K == 0) v0 = reluHalf4(0);
+                if constexpr (K == 1) { *reinterpret_cast<f16x4*>(outDst) = v0; v1 = reluHalf4(1); }
+                if constexpr (K == 2) { *reinterpret_cast<f16x4*>(outDst + 16) = v1; v2 = reluHalf4(2); }
+                if constexpr (K == 3) { *reinterpret_cast<f16x4*>(outDst + 32) = v2; v3 = reluHalf4(3); }
+                if constexpr (K == 4) { *reinterpret_cast<f16x4*>(outDst + 48) = v3; xin = toTensor(xinRaw); }
+                // conv6: D rows 0..2 (lanes 0..15) are R, G, B of pixel wave*16 + p16
+                if constexpr (K == 5) res = to_half4(acc6Prev[0], acc6Prev[1], acc6Prev[2], 0.0f);
+                if constexpr (K == 6)
+                    sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
+                                   (float)res[2] + (float)xin[2], 0.0f);
+                if constexpr (K == 7) c0 = unorm8((float)sum[0]);
+                if constexpr (K == 8) c1 = unorm8((float)sum[1]);
+                if constexpr (K == 9) c2 = unorm8((float)sum[2]);
+                if constexpr (K == 10)
+                    // branch-free: lanes that own no pixel store beyond the descriptor's range, which
+                    // the hardware drops
+                    __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc,
+                                                          int(outOff), 0, 0);
+            };
+
+            // ---- the MFMA stream: reads run kAhead in front, one epilogue piece per gap
+            f16x8 bq[27];
+            const f32x4 zero4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const auto body = [&](auto kk) {
+                constexpr int K = decltype(kk)::value;
+                if constexpr (K + kAhead < 27)
+                {
+                    // EXP & 64: half the reads (timing experiment)
+                    if constexpr ((EXP & 64) != 0 && ((K + kAhead) & 1)) bq[K + kAhead] = bq[K + kAhead - 1];
+                    else bq[K + kAhead] = readFrag(IC<K + kAhead>{});
+                }
+                // the first MFMA of each chain takes the bias (or zero) as its C operand
+                if constexpr (K == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[0], bq[0], bias, 0, 0, 0);
+                else if constexpr (K < 18) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[K], bq[K], acc, 0, 0, 0);
+                else if constexpr (K == 18) acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[0], bq[18], zero4, 0, 0, 0);
+                else acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[K - 18], bq[K], acc6, 0, 0, 0);
+                if constexpr ((EXP & 8) == 0 && !((EXP & 128) && K >= 5) && !((EXP & 1024) && K < 5)) piece(kk);
+                else if constexpr (K == 0) asm volatile("" ::"v"(accPrev), "v"(acc6Prev));
+                if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            };
+            bq[0] = readFrag(IC<0>{}); bq[1] = readFrag(IC<1>{}); bq[2] = readFrag(IC<2>{});
+            if constexpr (kAhead > 3) { bq[3] = readFrag(IC<3>{}); bq[4] = readFrag(IC<4>{}); bq[5] = readFrag(IC<5>{}); }
+            if constexpr (kAhead > 6) { bq[6] = readFrag(IC<6>{}); bq[7] = readFrag(IC<7>{}); bq[8] = readFrag(IC<8>{}); bq[9] = readFrag(IC<9>{}); }
+            if constexpr (kAhead > 10) { bq[10] = readFrag(IC<10>{}); bq[11] = readFrag(IC<11>{}); bq[12] = readFrag(IC<12>{}); bq[13] = readFrag(IC<13>{}); }
+            if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{}); body(IC<5>{});
+            body(IC<6>{}); body(IC<7>{}); body(IC<8>{}); body(IC<9>{}); body(IC<10>{}); body(IC<11>{});
+            body(IC<12>{}); body(IC<13>{}); body(IC<14>{}); body(IC<15>{}); body(IC<16>{}); body(IC<17>{});
+            body(IC<18>{}); body(IC<19>{}); body(IC<20>{}); body(IC<21>{}); body(IC<22>{}); body(IC<23>{});
+            body(IC<24>{}); body(IC<25>{}); body(IC<26>{});
+
+            // ---- park row t+2
+            if ((EXP & 32) == 0)
+            {
+                *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
+                *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
+            }
+            if ((EXP & 16) == 0) barrierLds();
+        };
+
+        // steps t0 .. Y1+7 (conv6's last row Y1-1 is finished by step Y1+6), rounded up to a multiple
+        // of four; surplus steps touch only ring rows nothing reads and store nothing
+        for (int t = t0; t <= Y1 + 6; t += 4)
+        {
+            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX, xinA, xinB, accA, accB, acc6A, acc6B);
+            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
+            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX, xinA, xinB, accA, accB, acc6A, acc6B);
+            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
+        }
+    }
+    if constexpr ((EXP & 2048) != 0)
+    {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) { p.stamps[blockIdx.x * 2] = c1 - c0; p.stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+    }
+}
+
+}  // namespace
+
+hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
+{
+    HrParams p{};
+    p.a4 = toDevice(l.a4);
+    p.input = l.input.base;
+    p.inputPitch = long(l.input.pitch);
+    p.inputFrame = long(l.input.frame);
+    p.wpk4 = reinterpret_cast<const f16x8*>(l.wpk4);
+    p.wpk5 = reinterpret_cast<const f16x8*>(l.wpk5);
+    p.wpk6 = reinterpret_cast<const f16x8*>(l.wpk6);
+    p.bias4 = l.bias4;
+    p.bias5 = l.bias5;
+    p.image = l.image.base;
+    p.imagePitch = long(l.image.pitch);
+    p.imageFrame = long(l.image.frame);
+    p.width2 = l.width2;
+    p.height2 = l.height2;
+    p.strips = (l.width2 + kHrStrip - 1) / kHrStrip;
+    // split the rows so that there are about two work items per CU; every segment re-computes
+    // 9 warm-up rows, so keep segments at least 32 rows tall
+    int segs = (2 * numCUs + p.strips * l.batch - 1) / (p.strips * l.batch);
+    const int maxSegs = l.height2 / 32 > 1 ? l.height2 / 32 : 1;
+    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
+    p.segRows = (l.height2 + segs - 1) / segs;
+    p.segs = (l.height2 + p.segRows - 1) / p.segRows;
+    p.numItems = p.strips * p.segs * l.batch;
+    if (p.numItems <= 0) return hipErrorInvalidValue;
+
+    const char* env = getenv("SRX_EXP");
+    const int exp = env ? atoi(env) : 0;
+    const char* envCu = getenv("SRX_HR_PER_CU");
+    const dim3 grid(gridFor(p.numItems, numCUs, envCu ? atoi(envCu) : 2)), block(kThreads);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
+#define SRX_HR_CASE(E)                                                                                       \
+    case E: {                                                                                                \
+        static bool attr[64] = {};                                                                           \
+        if (!attr[device])                                                                                   \
+        {                                                                                                    \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(HrFusedKernel<E>),        \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kHrSmem);   \
+            if (e != hipSuccess) return e;                                                                   \
+            attr[device] = true;                                                                             \
+        }                                                                                                    \
+        hipLaunchKernelGGL(HrFusedKernel<E>, grid, block, kHrSmem, s, p);                                    \
+        break;                                                                                               \
+    }
+    if (exp == 2048)
+    {
+        static unsigned long long* stamps = nullptr;
+        if (!stamps && hipMalloc(&stamps, 2 * 4096 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+        p.stamps = stamps;
+        static int calls = 0;
+        hipLaunchKernelGGL(HrFusedKernel<2048>, grid, block, kHrSmem, s, p);
+        if (++calls == 20)
+        {
+            hipStreamSynchronize(s);
+            static unsigned long long host[2 * 4096];
+            hipMemcpy(host, stamps, sizeof(unsigned long long) * 2 * grid.x, hipMemcpyDeviceToHost);
+            double sum = 0, mn = 1e30, mx = 0;
+            for (unsigned b = 0; b < grid.x; ++b)
+            {
+                const double ghz = double(host[2 * b]) / double(host[2 * b + 1]) * 0.1;
+                sum += ghz; mn = ghz < mn ? ghz : mn; mx = ghz > mx ? ghz : mx;
+            }
+            fprintf(stderr, "[srx] HR in-kernel clock: mean %.3f GHz (min %.3f max %.3f), cycles %llu, realtime ticks %llu\n",
+                    sum / grid.x, mn, mx, host[0], host[1]);
+        }
+        return hipGetLastError();
+    }
+    switch (exp)
+    {
+        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(4) SRX_HR_CASE(8) SRX_HR_CASE(16) SRX_HR_CASE(32)
+        SRX_HR_CASE(12) SRX_HR_CASE(28) SRX_HR_CASE(60) SRX_HR_CASE(56) SRX_HR_CASE(48)
+        SRX_HR_CASE(128) SRX_HR_CASE(1024) SRX_HR_CASE(36) SRX_HR_CASE(64) SRX_HR_CASE(256) SRX_HR_CASE(512) SRX_HR_CASE(768) SRX_HR_CASE(24) SRX_HR_CASE(40)
+    default:
+        SRX_HR_CASE(0)
+    }
+#undef SRX_HR_CASE
+    return hipGetLastError();
+}
+
+}  // namespace srx

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     // Waves w and w + 4 share a SIMD and its MFMA pipe and have the same amount of work per step;
     // left alone they run in lockstep (both in MFMAs, then both in epilogues with the pipe idle).
     // A static priority for one of them staggers the two.
-    if (EXP != 6 && role == 0) __builtin_amdgcn_s_setprio(1);
+    if (!(EXP & 32) && role == 0) __builtin_amdgcn_s_setprio(1);
 
     // pad columns of the rings are never written: they must hold finite values
     for (int i = tid * 16; i < kLrSmem; i += kLrThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv_up1, phase `wave`, row t - 6 ----
                 const int ru = t - 6;
-                if (ru >= Y0 && ru < Y1 && EXP != 2)
+                if (ru >= Y0 && ru < Y1 && !(EXP & 2))
                 {
                     const int py = wave >> 1, pxp = wave & 1;
 #pragma unroll
@@ -197,12 +197,15 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 #pragma unroll
                                 for (int cc = 0; cc < 4; ++cc)
                                 {
-                                    const f16x8 b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
+                                    f16x8 b;
+                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
+                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
                                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 4 + cc], b, acc, 0, 0, 0);
                                 }
                         }
                         interleaveHint<36, 1>();
 
+                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc)); continue; }
                         const int i = tile * 32 + px;
                         const int col = X0 + i;
                         f16x4 v[4];
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                                 d[4 * pair + k] = r[0];
                                 d[4 * pair + 2 + k] = r[1];
                             }
-                        if (i < kLrStrip && col < p.width && EXP != 1)
+                        if (i < kLrStrip && col < p.width && !(EXP & 1))
                         {
                             f16* dst = p.a4.base + f * p.a4.frame +
                                        (long(2 * ru + py) * p.a4.pitch + (2 * col + pxp)) * 32 + h * 8;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv3, outputs 32 * (wave - 4) .., row t - 4 ----
                 const int r3 = t - 4;
-                if (r3 >= Y0 - 1 && r3 <= Y1 && EXP != 3)
+                if (r3 >= Y0 - 1 && r3 <= Y1 && !(EXP & 4))
                 {
                     const int nt = wave - 4;
 #pragma unroll
@@ -255,12 +258,15 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 #pragma unroll
                                 for (int cc = 0; cc < 4; ++cc)
                                 {
-                                    const f16x8 b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
+                                    f16x8 b;
+                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
+                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
                                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 4 + cc], b, acc, 0, 0, 0);
                                 }
                         }
                         interleaveHint<36, 1>();
 
+                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc)); continue; }
                         const int k = tile * 32 + px;
                         const int col = X0 - 1 + k;
                         f16x4 v[4];
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 // ---- conv2, all 64 outputs, row t - 2 ----
                 const int r2 = t - 2;
-                if (r2 >= Y0 - 2 && r2 <= Y1 + 1 && EXP != 4)
+                if (r2 >= Y0 - 2 && r2 <= Y1 + 1 && !(EXP & 8))
                 {
 #pragma unroll
                     for (int tile = 0; tile < 2; ++tile)
@@ -291,13 +297,16 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 #pragma unroll
                                 for (int cc = 0; cc < 2; ++cc)
                                 {
-                                    const f16x8 b = *reinterpret_cast<const f16x8*>(base + j * kA1Stride + cc * 32);
+                                    f16x8 b;
+                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
+                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA1Stride + cc * 32);
                                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 2 + cc], b, acc0, 0, 0, 0);
                                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[18 + (i * 3 + j) * 2 + cc], b, acc1, 0, 0, 0);
                                 }
                         }
                         interleaveHint<18, 2>();
 
+                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc0), "v"(acc1)); continue; }
                         const int m = tile * 32 + px;
                         const int col = X0 - 2 + m;
                         const bool inside = r2 >= 0 && r2 < p.height && col >= 0 && col < p.width;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 const unsigned in0 = fetch(t + 3, lane);
                 const unsigned in1 = lane < 6 ? fetch(t + 3, 64 + lane) : 0u;
                 const int r1 = t;
-                if (r1 <= Y1 + 2 && EXP != 4)
+                if (r1 <= Y1 + 2 && !(EXP & 8))
                 {
 #pragma unroll
                     for (int tile = 0; tile < 3; ++tile)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 park(t + 3, lane, in0);
                 if (lane < 6) park(t + 3, 64 + lane, in1);
             }
-            if (EXP != 5) barrierLds();
+            if (!(EXP & 16)) barrierLds();
         }
     }
 }
@@ -394,16 +403,15 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     const char* env = getenv("SRX_EXP_LR");
     const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);
+#define SRX_LR_CASE(E) case E: hipLaunchKernelGGL(LrFusedKernel<E>, grid, block, kLrSmem, s, p); break;
     switch (exp)
     {
-    case 1: hipLaunchKernelGGL(LrFusedKernel<1>, grid, block, kLrSmem, s, p); break;
-    case 2: hipLaunchKernelGGL(LrFusedKernel<2>, grid, block, kLrSmem, s, p); break;
-    case 3: hipLaunchKernelGGL(LrFusedKernel<3>, grid, block, kLrSmem, s, p); break;
-    case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
-    case 5: hipLaunchKernelGGL(LrFusedKernel<5>, grid, block, kLrSmem, s, p); break;
-    case 6: hipLaunchKernelGGL(LrFusedKernel<6>, grid, block, kLrSmem, s, p); break;
-    default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
+        SRX_LR_CASE(1) SRX_LR_CASE(2) SRX_LR_CASE(4) SRX_LR_CASE(8) SRX_LR_CASE(16) SRX_LR_CASE(32) SRX_LR_CASE(64)
+        SRX_LR_CASE(128) SRX_LR_CASE(192) SRX_LR_CASE(208) SRX_LR_CASE(12) SRX_LR_CASE(14) SRX_LR_CASE(6) SRX_LR_CASE(10)
+    default:
+        SRX_LR_CASE(0)
     }
+#undef SRX_LR_CASE
     return hipGetLastError();
 }
 
