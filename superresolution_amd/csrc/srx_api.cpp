@@ -167,14 +167,35 @@ srx_status allocTensors(srx_ctx* c)
         c->tensorFrameBytes[id] = size_t(c->tensor[id].frame) * 2;
         if (id != SRX_T_INPUT) perFrame += c->tensorFrameBytes[id];
     }
-    // Frames resident per pass.  A large image fills the GPU on its own (its strips and row
-    // segments already make one work item per CU), so it runs one frame per pass and the
-    // workspace stays small; small images are batched into one launch per stage so that the
-    // launch still has work for every CU.  SRX_WORKSPACE_MB overrides.
-    size_t budget = size_t(256) << 20;
+    // Frames resident per pass.  Small images are batched into one launch per stage so that the
+    // launch has work for every CU (up to 256 MB of workspace).  A large image could fill the GPU
+    // on its own by cutting its rows into segments, but every segment re-computes the pipeline's
+    // warm-up rows; several frames per pass let the strips run the full height instead.  Among the
+    // pass sizes the workspace limit allows (8 GB, SRX_WORKSPACE_MB overrides) take the one with
+    // the least estimated MFMA time per frame: the low-resolution kernel issues 3.2x the MFMA
+    // cycles per row step of the high-resolution one, whose two workgroups per CU run together.
+    size_t limit = size_t(8) << 30;
     if (const char* env = std::getenv("SRX_WORKSPACE_MB"))
-        budget = std::max<size_t>(1, std::strtoull(env, nullptr, 10)) << 20;
-    uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, budget / std::max<size_t>(perFrame, 1))));
+        limit = std::max<size_t>(1, std::strtoull(env, nullptr, 10)) << 20;
+    perFrame = std::max<size_t>(perFrame, 1);
+    const uint32_t maxChunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, limit / perFrame)));
+    uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(maxChunk, (size_t(256) << 20) / perFrame)));
+    if (!c->keep())
+    {
+        double best = 0.0;
+        const uint32_t first = chunk, last = std::min<uint32_t>(maxChunk, chunk + 64);
+        for (uint32_t n = first; n <= last; ++n)
+        {
+            const srx::StripPlan lr = srx::PlanLrFused(int(c->width), int(c->height), int(n), c->numCUs);
+            const srx::StripPlan hr = srx::PlanHrFused(2 * int(c->width), 2 * int(c->height), int(n), c->numCUs);
+            const double cost = (3.2 * lr.steps * lr.rounds + 1.0 * hr.steps * hr.rounds) / n;
+            if (n == first || cost < best * 0.98)
+            {
+                best = cost;
+                chunk = n;
+            }
+        }
+    }
     if (c->keep() && chunk < c->batch)
         return fail(SRX_ERR_NOMEM, "SRX_FLAG_KEEP_TENSORS needs the whole batch resident; reduce batch");
     c->chunk = chunk;

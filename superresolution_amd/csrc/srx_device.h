@@ -78,6 +78,17 @@ __device__ __forceinline__ void barrierLds()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Diagnostic: when the environment variable SRX_CLOCK is set, a kernel's workgroups record how many
+// shader cycles and how many 100-MHz reference ticks they ran for, and the launcher prints the
+// resulting in-kernel clock after a number of launches.  The buffer is read by no kernel.
+struct ClockProbe
+{
+    unsigned long long* dev = nullptr;   // [2 * maxBlocks], or nullptr when the probe is off
+    int launches = 0;
+};
+unsigned long long* clockProbeBuffer(ClockProbe& probe, int blocks);
+void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream_t s);
+
 inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
 
 // Workgroups per launch: two per CU (or one when `perCU` is 1), a multiple of 8 so that the

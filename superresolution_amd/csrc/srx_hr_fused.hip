@@ -28,7 +28,6 @@
 // and PSTensorToImage.hlsl:14-35 + the R8G8B8A8_UNORM render target.
 #include "srx_device.h"
 
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -60,7 +59,7 @@ struct HrParams
     long imagePitch, imageFrame;
     int width2, height2;
     int strips, segs, segRows, numItems;
-    unsigned long long* stamps;      // diagnostic build only (EXP & 2048)
+    unsigned long long* clock;       // diagnostic (see ClockProbe), usually nullptr
 };
 
 template <int N>
@@ -79,8 +78,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates
     const int L = wave >> 1, ti = wave & 1;
 
-    unsigned long long c0 = 0, r0 = 0;
-    if constexpr ((EXP & 2048) != 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
     f16x8 wmain[18], w6[9];
     {
         const f16x8* src = L ? p.wpk5 : p.wpk4;
@@ -332,14 +330,33 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
             step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
         }
     }
-    if constexpr ((EXP & 2048) != 0)
+    if (p.clock && tid == 0)
     {
-        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) { p.stamps[blockIdx.x * 2] = c1 - c0; p.stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+        p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
     }
 }
 
 }  // namespace
+
+StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
+{
+    StripPlan pl;
+    if (width2 <= 0 || height2 <= 0 || batch <= 0 || numCUs <= 0) return pl;
+    pl.strips = (width2 + kHrStrip - 1) / kHrStrip;
+    // split the rows so that there are about two work items per CU (two workgroups share a CU); every
+    // segment re-computes 9 warm-up rows, so keep segments at least 32 rows tall
+    int segs = (2 * numCUs + pl.strips * batch - 1) / (pl.strips * batch);
+    const int maxSegs = height2 / 32 > 1 ? height2 / 32 : 1;
+    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
+    pl.segRows = (height2 + segs - 1) / segs;
+    pl.segs = (height2 + pl.segRows - 1) / pl.segRows;
+    pl.items = pl.strips * pl.segs * batch;
+    pl.steps = pl.segRows + 12;
+    const int slots = gridFor(pl.items, numCUs);
+    pl.rounds = (pl.items + slots - 1) / slots;
+    return pl;
+}
 
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
 {
@@ -358,15 +375,11 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.imageFrame = long(l.image.frame);
     p.width2 = l.width2;
     p.height2 = l.height2;
-    p.strips = (l.width2 + kHrStrip - 1) / kHrStrip;
-    // split the rows so that there are about two work items per CU; every segment re-computes
-    // 9 warm-up rows, so keep segments at least 32 rows tall
-    int segs = (2 * numCUs + p.strips * l.batch - 1) / (p.strips * l.batch);
-    const int maxSegs = l.height2 / 32 > 1 ? l.height2 / 32 : 1;
-    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
-    p.segRows = (l.height2 + segs - 1) / segs;
-    p.segs = (l.height2 + p.segRows - 1) / p.segRows;
-    p.numItems = p.strips * p.segs * l.batch;
+    const StripPlan plan = PlanHrFused(l.width2, l.height2, l.batch, numCUs);
+    p.strips = plan.strips;
+    p.segs = plan.segs;
+    p.segRows = plan.segRows;
+    p.numItems = plan.items;
     if (p.numItems <= 0) return hipErrorInvalidValue;
 
     const char* env = getenv("SRX_EXP");
@@ -388,29 +401,8 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
         hipLaunchKernelGGL(HrFusedKernel<E>, grid, block, kHrSmem, s, p);                                    \
         break;                                                                                               \
     }
-    if (exp == 2048)
-    {
-        static unsigned long long* stamps = nullptr;
-        if (!stamps && hipMalloc(&stamps, 2 * 4096 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
-        p.stamps = stamps;
-        static int calls = 0;
-        hipLaunchKernelGGL(HrFusedKernel<2048>, grid, block, kHrSmem, s, p);
-        if (++calls == 20)
-        {
-            hipStreamSynchronize(s);
-            static unsigned long long host[2 * 4096];
-            hipMemcpy(host, stamps, sizeof(unsigned long long) * 2 * grid.x, hipMemcpyDeviceToHost);
-            double sum = 0, mn = 1e30, mx = 0;
-            for (unsigned b = 0; b < grid.x; ++b)
-            {
-                const double ghz = double(host[2 * b]) / double(host[2 * b + 1]) * 0.1;
-                sum += ghz; mn = ghz < mn ? ghz : mn; mx = ghz > mx ? ghz : mx;
-            }
-            fprintf(stderr, "[srx] HR in-kernel clock: mean %.3f GHz (min %.3f max %.3f), cycles %llu, realtime ticks %llu\n",
-                    sum / grid.x, mn, mx, host[0], host[1]);
-        }
-        return hipGetLastError();
-    }
+    static ClockProbe probe;
+    p.clock = clockProbeBuffer(probe, int(grid.x));
     switch (exp)
     {
         SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(4) SRX_HR_CASE(8) SRX_HR_CASE(16) SRX_HR_CASE(32)
@@ -420,6 +412,7 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
         SRX_HR_CASE(0)
     }
 #undef SRX_HR_CASE
+    clockProbeReport(probe, "HrFusedKernel", int(grid.x), s);
     return hipGetLastError();
 }
 

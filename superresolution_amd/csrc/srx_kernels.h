@@ -81,6 +81,16 @@ struct LrFusedLaunch
 };
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 
+// How a fused kernel cuts `batch` frames into work items: strips of columns x segments of rows.
+// `steps` is the number of row steps one item takes (segment rows + the pipeline's warm-up rows) and
+// `rounds` how many items the busiest workgroup slot gets; steps * rounds / batch ranks plans.
+struct StripPlan
+{
+    int strips = 0, segs = 0, segRows = 0, items = 0, steps = 0, rounds = 0;
+};
+StripPlan PlanLrFused(int width, int height, int batch, int numCUs);
+StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
+
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s);

@@ -315,6 +315,33 @@ hipError_t launch3x3(const ConvParams& p, int numCUs, hipStream_t s)
 
 }  // namespace
 
+namespace dev {
+
+unsigned long long* clockProbeBuffer(ClockProbe& probe, int blocks)
+{
+    static const bool on = getenv("SRX_CLOCK") != nullptr;
+    if (!on || blocks > 4096) return nullptr;
+    if (!probe.dev && hipMalloc(&probe.dev, 2 * 4096 * sizeof(unsigned long long)) != hipSuccess) probe.dev = nullptr;
+    return probe.dev;
+}
+
+void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream_t s)
+{
+    if (!probe.dev || ++probe.launches != 40) return;
+    if (hipStreamSynchronize(s) != hipSuccess) return;
+    static unsigned long long host[2 * 4096];
+    if (hipMemcpy(host, probe.dev, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    double sum = 0, cyc = 0;
+    for (int b = 0; b < blocks; ++b)
+    {
+        sum += double(host[2 * b]) / double(host[2 * b + 1]) * 0.1;
+        cyc += double(host[2 * b]);
+    }
+    fprintf(stderr, "[srx] %s: in-kernel clock %.3f GHz, %.0f cycles per workgroup\n", name, sum / blocks, cyc / blocks);
+}
+
+}  // namespace dev
+
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s)
 {
     const long total = long(width) * height * batch;

@@ -2,17 +2,27 @@
 //
 // One workgroup of eight waves walks a strip of kLrStrip low-resolution columns
 // downwards, one row per step, keeping rolling windows of the packed input and
-// of the conv1 / conv2 / conv3 activations in LDS rings (104 KB).  Nothing but the
+// of the conv1 / conv2 / conv3 activations in LDS rings (121 KB).  Nothing but the
 // 8-bit input image is read from HBM and nothing but conv_up1's output is
-// written.  Per step the layers work on different rows, one barrier per step:
-//     conv1 row t | conv2 row t-2 | conv3 row t-4 | conv_up1 row t-6
-// Every wave keeps the filter fragments of its share resident in VGPRs:
-//     waves 0-3  conv_up1, output phase = wave   (36 fragments, 72 MFMAs / step)
-//     waves 4-5  conv3, 32 of the 64 outputs     (36 fragments, 72 MFMAs / step)
-//     wave  6    conv2, all 64 outputs           (36 fragments, 72 MFMAs / step)
-//     wave  7    conv1 + the input row loader    (10 fragments, 30 MFMAs / step)
+// written.  Every wave keeps the filter fragments of its share resident in VGPRs
+// and runs chains of v_mfma_f32_32x32x16_f16 over 32-pixel tiles, one 1-KiB
+// ds_read_b128 of activations per MFMA:
+//     waves 0-3  conv_up1, output phase = wave   2 chains of 36 MFMAs per step
+//     waves 4-5  conv3, 32 of the 64 outputs     2 chains of 36
+//     wave  6    conv2, all 64 outputs           4 chains of 18
+//     wave  7    conv1 + the input row loader    3 chains of 10
 // Waves w and w+4 share a SIMD, so every SIMD issues 144 MFMAs per step (102 for
 // the last pair).
+//
+// Software pipeline.  A chain's results are converted and stored while the NEXT
+// chain of the same wave runs, a few instructions in each gap between its MFMAs,
+// and the first activation fragments of the next chain are fetched during the
+// last MFMAs of the current one (across the step barrier too: they come from a
+// row that was complete a step earlier).  So a wave's MFMA stream never pauses
+// for an epilogue or for LDS latency inside a step.  The last chain of a step
+// is finished during the next step, which is why each layer trails its producer
+// by three rows rather than two:
+//     conv1 row t | conv2 row t-2 | conv3 row t-5 | conv_up1 row t-8
 //
 // Column bookkeeping for a strip whose first output column is X0:
 //   conv_up1 pixel i = column X0 + i (60 of 64 kept), reads a3 index i..i+2
@@ -26,6 +36,8 @@
 #include "srx_device.h"
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace srx {
 
@@ -41,10 +53,11 @@ constexpr int kA1Stride = 80, kA1Row = 66 * kA1Stride;
 constexpr int kA2Stride = 144, kA2Row = 66 * kA2Stride;
 constexpr int kBiasUp = 0, kBiasC3 = 32, kBiasC2 = 96, kBiasC1 = 160;   // floats into the bias table
 constexpr int kX0Off = 192 * 4;
-constexpr int kA1Off = kX0Off + 8 * kX0Row;
+constexpr int kA1Off = kX0Off + 8 * kX0Row;     // x0: 8 slots, a1: 4 slots, a2 and a3: 5 slots
 constexpr int kA2Off = kA1Off + 4 * kA1Row;
-constexpr int kA3Off = kA2Off + 4 * kA2Row;
-constexpr int kLrSmem = kA3Off + 4 * kA2Row;    // 104576
+constexpr int kA3Off = kA2Off + 5 * kA2Row;
+constexpr int kLrSmem = kA3Off + 5 * kA2Row;    // 123584
+constexpr int kAhead = 4;                       // LDS reads in flight ahead of their MFMA
 
 struct LrParams
 {
@@ -55,7 +68,22 @@ struct LrParams
     const float* bias;          // conv_up1[32] | conv3[64] | conv2[64] | conv1[32]
     int width, height;
     int strips, segs, segRows, numItems;
+    unsigned long long* clock;  // diagnostic (see ClockProbe), usually nullptr
 };
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void forEachIdx(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void forEach(F&& f) { forEachIdx(f, std::make_integer_sequence<int, N>{}); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Slot of row r in a ring of five rows (r >= -5000).  The value is made opaque so that the compiler
+// cannot distribute the multiplication by the row size over it: ring addresses then stay a VGPR base
+// plus an immediate that fits the 16-bit offset field of ds_read / ds_write.
+__device__ __forceinline__ int slot5(int r) { return __builtin_amdgcn_readfirstlane(int(unsigned(r + 5000) % 5u)); }
 
 // Initial accumulator = bias of output rows (q & 3) + 8 * (q >> 2) + 4 * h, from the LDS table.
 __device__ __forceinline__ f32x16 biasAcc(const char* smem, int tableOff, int h)
@@ -71,40 +99,47 @@ __device__ __forceinline__ f32x16 biasAcc(const char* smem, int tableOff, int h)
     return acc;
 }
 
-// ReLU + fp16 of the 16 accumulators of one lane, as four packed groups of four channels
-// (group g = channels 8g + 4h .. 8g + 4h + 3); zero when the pixel lies outside the image.
-__device__ __forceinline__ void reluPack(const f32x16& acc, bool inside, f16x4 (&out)[4])
+// ReLU + fp16 of accumulators 4g .. 4g+3 of one lane (channels 8g + 4h .. 8g + 4h + 3).
+__device__ __forceinline__ f16x4 reluHalf4(const f32x16& acc, int g)
 {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-    {
-        f16x4 v = to_half4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-        v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
-        out[g] = inside ? v : f16x4{0, 0, 0, 0};
-    }
+    const f16x4 v = to_half4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    return __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
 }
 
-// K-loop scheduling hint: keep `ahead` LDS reads in flight in front of the MFMAs that consume
-// them; `perRead` MFMAs follow every read.
-// The bias reads that seed the accumulators are LDS reads too and come first.
-template <int READS, int PER_READ>
-__device__ __forceinline__ void interleaveHint()
+// The first kAhead activation fragments of a chain, fetched while the chain before it runs.
+struct Frags
 {
-    constexpr int kAhead = 8;
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 * PER_READ + kAhead, 0);
-#pragma unroll
-    for (int k = 0; k < READS - kAhead; ++k)
-    {
-        __builtin_amdgcn_sched_group_barrier(0x008, PER_READ, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, kAhead * PER_READ, 0);
+    f16x8 v[kAhead];
+};
+
+// One chain of N MFMAs into `acc` (already holding the bias).  Fragment k of the B operand is
+// rd(k) and its filter fragment w(k); the first kAhead fragments arrive in `pre`, and the first
+// kAhead of the following chain, rdNext(k), leave in it.  piece(k) is issued in the gap after
+// MFMA k: that is where the previous chain's epilogue runs.
+template <int N, bool PIN, class W, class RD, class RDN, class PC>
+__device__ __forceinline__ void mfmaChain(f32x16& acc, Frags& pre, W&& w, RD&& rd, RDN&& rdNext, PC&& piece)
+{
+    f16x8 bq[N];
+    Frags nxt;
+    forEach<N>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        if constexpr (K + kAhead < N) bq[K + kAhead] = rd(IC<K + kAhead>{});
+        else nxt.v[K + kAhead - N] = rdNext(IC<K + kAhead - N>{});
+        if constexpr (K < kAhead) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w(kk), pre.v[K], acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w(kk), bq[K], acc, 0, 0, 0);
+        piece(kk);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    });
+    pre = nxt;
 }
 
+// EXP: 1 = no scheduling pins; 16 = no step barrier (timing only); 32 = no static priority.
 template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool PIN = (EXP & 1) == 0;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -127,15 +162,16 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         for (int s = 0; s < 36; ++s) asm volatile("" ::"v"(wreg[s]));
     }
 
-    // Waves w and w + 4 share a SIMD and its MFMA pipe and have the same amount of work per step;
-    // left alone they run in lockstep (both in MFMAs, then both in epilogues with the pipe idle).
-    // A static priority for one of them staggers the two.
+    // Waves w and w + 4 share a SIMD and its MFMA pipe; a static priority for one of them keeps the
+    // two from settling into lockstep.
     if (!(EXP & 32) && role == 0) __builtin_amdgcn_s_setprio(1);
 
     // pad columns of the rings are never written: they must hold finite values
     for (int i = tid * 16; i < kLrSmem; i += kLrThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
     __syncthreads();
     if (tid < 192) reinterpret_cast<float*>(smem)[tid] = p.bias[tid];
+
+    const auto stepBarrier = [] { if (!(EXP & 16)) barrierLds(); };
 
     const int perFrame = p.strips * p.segs;
     for (TileWalk tw(p.numItems); tw.valid(); tw.next())
@@ -146,6 +182,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         const int X0 = (rem - seg * p.strips) * kLrStrip;
         const int Y0 = seg * p.segRows;
         const int Y1 = min(p.height, Y0 + p.segRows);
+        const int t0 = Y0 - 3, tEnd = Y1 + 8;
         const uint8_t* img = p.image + f * p.imageFrame;
 
         // input loader (wave 7): row `row`, x0 index e -> column X0 - 5 + e, zero outside the image
@@ -163,7 +200,6 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         };
 
         __syncthreads();
-        const int t0 = Y0 - 3;
         if (role == 3)
         {
 #pragma unroll
@@ -175,52 +211,46 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         }
         __syncthreads();
 
-        for (int t = t0; t <= Y1 + 5; ++t)
+        if (role == 0)
         {
-            if (role == 0)
+            // ---- conv_up1, phase `wave`: row ru = t - 8, rows Y0 .. Y1-1 (+ one step to finish the last tile)
+            const int py = wave >> 1, pxp = wave & 1;
+            const int laneRd = kA3Off + px * kA2Stride + h * 16;       // + tile * 32 * kA2Stride + tap offsets
+            // byte offset of this lane's 16 B within an a4 row, per tile; lanes that own no pixel get an
+            // offset no buffer descriptor covers, so their stores are dropped
+            unsigned laneSt[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
             {
-                // ---- conv_up1, phase `wave`, row t - 6 ----
-                const int ru = t - 6;
-                if (ru >= Y0 && ru < Y1 && !(EXP & 2))
+                const int i = T * 32 + px, col = X0 + i;
+                laneSt[T] = (i < kLrStrip && col < p.width) ? unsigned((2 * col + pxp) * 64 + h * 16) : 0xC0000000u;
+            }
+            const long rowBytes = long(p.a4.pitch) * 64;
+            char* a4f = reinterpret_cast<char*>(p.a4.base + f * p.a4.frame);
+            f32x16 accA = biasAcc(smem, kBiasUp, h), accB = accA;
+            Frags pre;
+            for (int t = t0; t <= tEnd; ++t)
+            {
+                const int ru = t - 8;
+                if (ru >= Y0 && ru <= Y1)
                 {
-                    const int py = wave >> 1, pxp = wave & 1;
-#pragma unroll
-                    for (int tile = 0; tile < 2; ++tile)
-                    {
-                        f32x16 acc = biasAcc(smem, kBiasUp, h);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
+                    // finish a tile: ReLU, fp16, widen to 8 consecutive channels per lane, two 16-B stores
+                    unsigned d[8];
+                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T, bool rowValid) {
+                        constexpr int K = decltype(kk)::value;
+                        if constexpr ((EXP & 8) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
+                        if constexpr (K >= 2 && K <= 14 && (K - 2) % 4 == 0)
                         {
-                            const char* base = smem + kA3Off + ((ru + i - 1) & 3) * kA2Row + (tile * 32 + px) * kA2Stride + h * 16;
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                                for (int cc = 0; cc < 4; ++cc)
-                                {
-                                    f16x8 b;
-                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
-                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 4 + cc], b, acc, 0, 0, 0);
-                                }
-                        }
-                        interleaveHint<36, 1>();
-
-                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc)); continue; }
-                        const int i = tile * 32 + px;
-                        const int col = X0 + i;
-                        f16x4 v[4];
-                        reluPack(acc, true, v);
-                        // widen the stores: after the half-wave swaps a lane holds 8 consecutive channels
-                        unsigned d[8];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                        {
-                            const uint2 u = *reinterpret_cast<const uint2*>(&v[g]);
+                            constexpr int g = (K - 2) / 4;
+                            const f16x4 v = reluHalf4(acc, g);
+                            const uint2 u = *reinterpret_cast<const uint2*>(&v);
                             d[2 * g] = u.x;
                             d[2 * g + 1] = u.y;
                         }
-#pragma unroll
-                        for (int pair = 0; pair < 2; ++pair)
+                        if constexpr (K == 18 || K == 22)
+                        {
+                            // after the half-wave swaps a lane holds 8 consecutive channels
+                            constexpr int pair = (K - 18) / 4;
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
                             {
@@ -228,106 +258,195 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                                 d[4 * pair + k] = r[0];
                                 d[4 * pair + 2 + k] = r[1];
                             }
-                        if (i < kLrStrip && col < p.width && !(EXP & 1))
-                        {
-                            f16* dst = p.a4.base + f * p.a4.frame +
-                                       (long(2 * ru + py) * p.a4.pitch + (2 * col + pxp)) * 32 + h * 8;
-                            *reinterpret_cast<uint4*>(dst) = uint4{d[0], d[1], d[2], d[3]};
-                            *reinterpret_cast<uint4*>(dst + 16) = uint4{d[4], d[5], d[6], d[7]};
                         }
-                    }
-                }
-            }
-            else if (role == 1)
-            {
-                // ---- conv3, outputs 32 * (wave - 4) .., row t - 4 ----
-                const int r3 = t - 4;
-                if (r3 >= Y0 - 1 && r3 <= Y1 && !(EXP & 4))
-                {
-                    const int nt = wave - 4;
-#pragma unroll
-                    for (int tile = 0; tile < 2; ++tile)
+                        if constexpr (K == 26)
+                        {
+                            // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
+                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                                a4f + (2 * row + py) * rowBytes, 0, (rowValid && !(EXP & 2)) ? int(rowBytes) : 0, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T]), 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4], d[5], d[6], d[7]}, rs, int(laneSt[T] + 32u), 0, 0);
+                        }
+                    };
+                    if (ru < Y1)
                     {
-                        f32x16 acc = biasAcc(smem, kBiasC3 + nt * 32, h);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                        {
-                            const char* base = smem + kA2Off + ((r3 + i - 1) & 3) * kA2Row + (tile * 32 + px) * kA2Stride + h * 16;
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                                for (int cc = 0; cc < 4; ++cc)
-                                {
-                                    f16x8 b;
-                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
-                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA2Stride + cc * 32);
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 4 + cc], b, acc, 0, 0, 0);
-                                }
-                        }
-                        interleaveHint<36, 1>();
-
-                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc)); continue; }
-                        const int k = tile * 32 + px;
-                        const int col = X0 - 1 + k;
-                        f16x4 v[4];
-                        reluPack(acc, r3 >= 0 && r3 < p.height && col >= 0 && col < p.width, v);
-                        char* dst = smem + kA3Off + (r3 & 3) * kA2Row + k * kA2Stride + nt * 64 + h * 8;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f16x4*>(dst + g * 16) = v[g];
+                        const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
+                                  b2 = laneRd + slot5(ru + 1) * kA2Row;
+                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                            constexpr int K = decltype(kk)::value;
+                            constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+                        };
+                        const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+                        if (ru == Y0)
+                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
+                        // tile 0; finishes tile 1 of the previous row
+                        mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) {
+                                               finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
+                                               if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasUp, h);
+                                           });
+                        // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
+                        // first fragments come from row ru (slot b1)
+                        mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                           [&](auto kk) {
+                                               finish(kk, accA, ru, 0, true);
+                                               if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasUp, h);
+                                           });
                     }
+                    else
+                        forEach<27>([&](auto kk) { finish(kk, accB, ru - 1, 1, true); });
                 }
+                stepBarrier();
             }
-            else if (role == 2)
+        }
+        else if (role == 1)
+        {
+            // ---- conv3, outputs 32 * (wave - 4) ..: row r3 = t - 5, rows Y0-1 .. Y1
+            const int nt = wave - 4;
+            const int laneRd = kA2Off + px * kA2Stride + h * 16;
+            const int laneWr = kA3Off + px * kA2Stride + nt * 64 + h * 8;
+            bool colInside[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) colInside[T] = X0 - 1 + T * 32 + px >= 0 && X0 - 1 + T * 32 + px < p.width;
+            f32x16 accA = biasAcc(smem, kBiasC3 + nt * 32, h), accB = accA;
+            Frags pre;
+            for (int t = t0; t <= tEnd; ++t)
             {
-                // ---- conv2, all 64 outputs, row t - 2 ----
+                const int r3 = t - 5;
+                if (r3 >= Y0 - 1 && r3 <= Y1 + 1)
+                {
+                    f16x4 v;
+                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T) {
+                        constexpr int K = decltype(kk)::value;
+                        if constexpr ((EXP & 4) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
+                        if constexpr (K >= 2 && K <= 30 && (K - 2) % 8 == 0)
+                        {
+                            const bool inside = colInside[T] && row >= 0 && row < p.height;
+                            v = reluHalf4(acc, (K - 2) / 8);
+                            v = inside ? v : f16x4{0, 0, 0, 0};
+                        }
+                        if constexpr (K >= 6 && K <= 30 && (K - 6) % 8 == 0)
+                            *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + ((K - 6) / 8) * 16) = v;
+                    };
+                    if (r3 <= Y1)
+                    {
+                        const int b0 = laneRd + slot5(r3 - 1) * kA2Row, b1 = laneRd + slot5(r3) * kA2Row,
+                                  b2 = laneRd + slot5(r3 + 1) * kA2Row;
+                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                            constexpr int K = decltype(kk)::value;
+                            constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+                        };
+                        const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+                        if (r3 == Y0 - 1)
+                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
+                        mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) {
+                                               finish(kk, accB, r3 - 1, 1);
+                                               if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasC3 + nt * 32, h);
+                                           });
+                        mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                           [&](auto kk) {
+                                               finish(kk, accA, r3, 0);
+                                               if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasC3 + nt * 32, h);
+                                           });
+                    }
+                    else
+                        forEach<31>([&](auto kk) { finish(kk, accB, r3 - 1, 1); });
+                }
+                stepBarrier();
+            }
+        }
+        else if (role == 2)
+        {
+            // ---- conv2, all 64 outputs as four chains (tile, half of the outputs): row r2 = t - 2, rows Y0-2 .. Y1+1
+            const int laneRd = kA1Off + px * kA1Stride + h * 16;
+            const int laneWr = kA2Off + px * kA2Stride + h * 8;
+            bool colInside[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) colInside[T] = X0 - 2 + T * 32 + px >= 0 && X0 - 2 + T * 32 + px < p.width;
+            f32x16 acc0 = biasAcc(smem, kBiasC2, h), acc1 = biasAcc(smem, kBiasC2 + 32, h);
+            Frags pre;
+            for (int t = t0; t <= tEnd; ++t)
+            {
                 const int r2 = t - 2;
-                if (r2 >= Y0 - 2 && r2 <= Y1 + 1 && !(EXP & 8))
+                if (r2 >= Y0 - 2 && r2 <= Y1 + 2)
                 {
-#pragma unroll
-                    for (int tile = 0; tile < 2; ++tile)
-                    {
-                        f32x16 acc0 = biasAcc(smem, kBiasC2, h);
-                        f32x16 acc1 = biasAcc(smem, kBiasC2 + 32, h);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
+                    f16x4 v;
+                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T, int half) {
+                        constexpr int K = decltype(kk)::value;
+                        if constexpr ((EXP & 4) != 0) { if constexpr (K == 1) asm volatile("" ::"v"(acc)); return; }
+                        if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
                         {
-                            const char* base = smem + kA1Off + ((r2 + i - 1) & 3) * kA1Row + (tile * 32 + px) * kA1Stride + h * 16;
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                                for (int cc = 0; cc < 2; ++cc)
-                                {
-                                    f16x8 b;
-                                    if constexpr ((EXP & 64) != 0) { b = wreg[cc]; asm volatile("" : "+v"(b)); }
-                                    else b = *reinterpret_cast<const f16x8*>(base + j * kA1Stride + cc * 32);
-                                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(i * 3 + j) * 2 + cc], b, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[18 + (i * 3 + j) * 2 + cc], b, acc1, 0, 0, 0);
-                                }
+                            const bool inside = colInside[T] && row >= 0 && row < p.height;
+                            v = reluHalf4(acc, (K - 1) / 4);
+                            v = inside ? v : f16x4{0, 0, 0, 0};
                         }
-                        interleaveHint<18, 2>();
-
-                        if constexpr ((EXP & 128) != 0) { asm volatile("" ::"v"(acc0), "v"(acc1)); continue; }
-                        const int m = tile * 32 + px;
-                        const int col = X0 - 2 + m;
-                        const bool inside = r2 >= 0 && r2 < p.height && col >= 0 && col < p.width;
-                        f16x4 v[4];
-                        char* dst = smem + kA2Off + (r2 & 3) * kA2Row + m * kA2Stride + h * 8;
-                        reluPack(acc0, inside, v);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f16x4*>(dst + g * 16) = v[g];
-                        reluPack(acc1, inside, v);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f16x4*>(dst + 64 + g * 16) = v[g];
+                        if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
+                            *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + half * 64 + ((K - 3) / 4) * 16) = v;
+                    };
+                    if (r2 <= Y1 + 1)
+                    {
+                        const int b0 = laneRd + ((r2 - 1) & 3) * kA1Row, b1 = laneRd + (r2 & 3) * kA1Row,
+                                  b2 = laneRd + ((r2 + 1) & 3) * kA1Row;
+                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                            constexpr int K = decltype(kk)::value;
+                            constexpr int i = K / 6, j = (K / 2) % 3, cc = K % 2;
+                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA1Stride + j * kA1Stride + cc * 32);
+                        };
+                        const auto wLo = [&](auto kk) { return wreg[decltype(kk)::value]; };
+                        const auto wHi = [&](auto kk) { return wreg[18 + decltype(kk)::value]; };
+                        if (r2 == Y0 - 2)
+                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
+                        // (tile 0, outputs 0-31); finishes (tile 1, outputs 32-63) of the previous row
+                        mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                           [&](auto kk) {
+                                               finish(kk, acc1, r2 - 1, 1, 1);
+                                               if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
+                                           });
+                        mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) {
+                                               finish(kk, acc0, r2, 0, 0);
+                                               if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
+                                           });
+                        mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) {
+                                               finish(kk, acc1, r2, 0, 1);
+                                               if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
+                                           });
+                        mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                           [&](auto kk) {
+                                               finish(kk, acc0, r2, 1, 0);
+                                               if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
+                                           });
                     }
+                    else
+                        forEach<16>([&](auto kk) { finish(kk, acc1, r2 - 1, 1, 1); });
                 }
+                stepBarrier();
             }
-            else
+        }
+        else
+        {
+            // ---- conv1 (row t, rows Y0-3 .. Y1+2) and the input row t + 3 (issued first, parked after the MFMAs)
+            for (int t = t0; t <= tEnd; ++t)
             {
-                // ---- the input row t + 3 (issue now, park after the MFMAs) and conv1, row t ----
                 const unsigned in0 = fetch(t + 3, lane);
                 const unsigned in1 = lane < 6 ? fetch(t + 3, 64 + lane) : 0u;
                 const int r1 = t;
-                if (r1 <= Y1 + 2 && !(EXP & 8))
+                if (r1 <= Y1 + 2)
                 {
 #pragma unroll
                     for (int tile = 0; tile < 3; ++tile)
@@ -349,25 +468,51 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                         }
                         const int n = tile * 32 + px;
                         const int col = X0 - 3 + n;
-                        f16x4 v[4];
-                        reluPack(acc, r1 >= 0 && r1 < p.height && col >= 0 && col < p.width, v);
+                        const bool inside = r1 >= 0 && r1 < p.height && col >= 0 && col < p.width;
                         if (n < 66)
                         {
                             char* dst = smem + kA1Off + (r1 & 3) * kA1Row + n * kA1Stride + h * 8;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) *reinterpret_cast<f16x4*>(dst + g * 16) = v[g];
+                            for (int g = 0; g < 4; ++g)
+                            {
+                                const f16x4 v = reluHalf4(acc, g);
+                                *reinterpret_cast<f16x4*>(dst + g * 16) = inside ? v : f16x4{0, 0, 0, 0};
+                            }
                         }
                     }
                 }
                 park(t + 3, lane, in0);
                 if (lane < 6) park(t + 3, 64 + lane, in1);
+                stepBarrier();
             }
-            if (!(EXP & 16)) barrierLds();
         }
+    }
+    if (p.clock && tid == 0)
+    {
+        p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
     }
 }
 
 }  // namespace
+
+StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
+{
+    StripPlan pl;
+    if (width <= 0 || height <= 0 || batch <= 0 || numCUs <= 0) return pl;
+    pl.strips = (width + kLrStrip - 1) / kLrStrip;
+    // one work item per CU where the image allows it; a segment re-computes 12 warm-up rows
+    int segs = (numCUs + pl.strips * batch / 2) / (pl.strips * batch);
+    const int maxSegs = height / 32 > 1 ? height / 32 : 1;
+    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
+    pl.segRows = (height + segs - 1) / segs;
+    pl.segs = (height + pl.segRows - 1) / pl.segRows;
+    pl.items = pl.strips * pl.segs * batch;
+    pl.steps = pl.segRows + 12;
+    const int slots = gridFor(pl.items, numCUs, 1);
+    pl.rounds = (pl.items + slots - 1) / slots;
+    return pl;
+}
 
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
 {
@@ -383,35 +528,43 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     p.bias = l.bias;
     p.width = l.width;
     p.height = l.height;
-    p.strips = (l.width + kLrStrip - 1) / kLrStrip;
-    // one work item per CU where the image allows it; a segment re-computes 9 warm-up rows
-    int segs = (numCUs + p.strips * l.batch / 2) / (p.strips * l.batch);
-    const int maxSegs = l.height / 32 > 1 ? l.height / 32 : 1;
-    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
-    p.segRows = (l.height + segs - 1) / segs;
-    p.segs = (l.height + p.segRows - 1) / p.segRows;
-    p.numItems = p.strips * p.segs * l.batch;
+    const StripPlan plan = PlanLrFused(l.width, l.height, l.batch, numCUs);
+    p.strips = plan.strips;
+    p.segs = plan.segs;
+    p.segRows = plan.segRows;
+    p.numItems = plan.items;
     if (p.numItems <= 0) return hipErrorInvalidValue;
-    // raise the dynamic LDS limit once per device
-    static bool attr[64] = {};
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
-    if (!attr[device])
-    {
-        attr[device] = true;
-    }
+    // a row of a4 must be addressable with a 32-bit byte offset
+    if (long(l.a4.pitch) * 64 >= (1L << 31)) return hipErrorInvalidValue;
+
     const char* env = getenv("SRX_EXP_LR");
     const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);
-#define SRX_LR_CASE(E) case E: hipLaunchKernelGGL(LrFusedKernel<E>, grid, block, kLrSmem, s, p); break;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
+    static ClockProbe probe;
+    p.clock = clockProbeBuffer(probe, int(grid.x));
+#define SRX_LR_CASE(E)                                                                                       \
+    case E: {                                                                                                \
+        static bool attr[64] = {};                                                                           \
+        if (!attr[device])                                                                                   \
+        {                                                                                                    \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(LrFusedKernel<E>),        \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLrSmem);   \
+            if (e != hipSuccess) return e;                                                                   \
+            attr[device] = true;                                                                             \
+        }                                                                                                    \
+        hipLaunchKernelGGL(LrFusedKernel<E>, grid, block, kLrSmem, s, p);                                    \
+        break;                                                                                               \
+    }
     switch (exp)
     {
-        SRX_LR_CASE(1) SRX_LR_CASE(2) SRX_LR_CASE(4) SRX_LR_CASE(8) SRX_LR_CASE(16) SRX_LR_CASE(32) SRX_LR_CASE(64)
-        SRX_LR_CASE(128) SRX_LR_CASE(192) SRX_LR_CASE(208) SRX_LR_CASE(12) SRX_LR_CASE(14) SRX_LR_CASE(6) SRX_LR_CASE(10)
+        SRX_LR_CASE(1) SRX_LR_CASE(16) SRX_LR_CASE(32) SRX_LR_CASE(2) SRX_LR_CASE(4) SRX_LR_CASE(8) SRX_LR_CASE(12) SRX_LR_CASE(6)
     default:
         SRX_LR_CASE(0)
     }
 #undef SRX_LR_CASE
+    clockProbeReport(probe, "LrFusedKernel", int(grid.x), s);
     return hipGetLastError();
 }
 
