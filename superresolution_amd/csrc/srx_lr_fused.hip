@@ -69,6 +69,7 @@ struct LrParams
     int width, height;
     int strips, segs, segRows, numItems;
     unsigned long long* clock;  // diagnostic (see ClockProbe), usually nullptr
+    int prioMask;               // bit r: waves of role r run at priority 1
 };
 
 template <int N>
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         for (int s = 0; s < 36; ++s) asm volatile("" ::"v"(wreg[s]));
     }
 
-    // Waves w and w + 4 share a SIMD and its MFMA pipe; a static priority for one of them keeps the
-    // two from settling into lockstep.
-    if (!(EXP & 32) && role == 0) __builtin_amdgcn_s_setprio(1);
+    // Waves w and w + 4 share a SIMD and its MFMA pipe.  The second-dispatched half (waves 4-7) loses
+    // the issue arbitration by age; a static priority for it measured best (the conv_up1 waves have
+    // the most slack at the step barrier).
+    if ((p.prioMask >> role) & 1) __builtin_amdgcn_s_setprio(1);
 
     // pad columns of the rings are never written: they must hold finite values
     for (int i = tid * 16; i < kLrSmem; i += kLrThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 
         if (role == 0)
         {
-            // ---- conv_up1, phase `wave`: row ru = t - 8, rows Y0 .. Y1-1 (+ one step to finish the last tile)
+            // ---- conv_up1, phase `wave`: row ru at step ru + 8, rows Y0 .. Y1-1, and one more step
+            // to finish the last tile
             const int py = wave >> 1, pxp = wave & 1;
             const int laneRd = kA3Off + px * kA2Stride + h * 16;       // + tile * 32 * kA2Stride + tap offsets
             // byte offset of this lane's 16 B within an a4 row, per tile; lanes that own no pixel get an
@@ -227,216 +230,215 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             }
             const long rowBytes = long(p.a4.pitch) * 64;
             char* a4f = reinterpret_cast<char*>(p.a4.base + f * p.a4.frame);
+            // finish a tile: ReLU, fp16, widen to 8 consecutive channels per lane, two 16-B stores
+            unsigned d[8];
+            const auto finish = [&](auto kk, const f32x16& acc, int row, int T, bool rowValid) {
+                constexpr int K = decltype(kk)::value;
+                if constexpr ((EXP & 8) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
+                if constexpr (K >= 2 && K <= 14 && (K - 2) % 4 == 0)
+                {
+                    constexpr int g = (K - 2) / 4;
+                    const f16x4 v = reluHalf4(acc, g);
+                    const uint2 u = *reinterpret_cast<const uint2*>(&v);
+                    d[2 * g] = u.x;
+                    d[2 * g + 1] = u.y;
+                }
+                if constexpr (K == 18 || K == 22)
+                {
+                    // after the half-wave swaps a lane holds 8 consecutive channels
+                    constexpr int pair = (K - 18) / 4;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                    {
+                        const auto r = __builtin_amdgcn_permlane32_swap(d[4 * pair + k], d[4 * pair + 2 + k], false, false);
+                        d[4 * pair + k] = r[0];
+                        d[4 * pair + 2 + k] = r[1];
+                    }
+                }
+                if constexpr (K == 26)
+                {
+                    // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        a4f + (2 * row + py) * rowBytes, 0, (rowValid && !(EXP & 2)) ? int(rowBytes) : 0, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T]), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4], d[5], d[6], d[7]}, rs, int(laneSt[T] + 32u), 0, 0);
+                }
+            };
+            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                constexpr int K = decltype(kk)::value;
+                constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+                const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+            };
+            const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+
+            int t = t0;
+            for (; t < Y0 + 8; ++t) stepBarrier();
             f32x16 accA = biasAcc(smem, kBiasUp, h), accB = accA;
             Frags pre;
-            for (int t = t0; t <= tEnd; ++t)
             {
-                const int ru = t - 8;
-                if (ru >= Y0 && ru <= Y1)
-                {
-                    // finish a tile: ReLU, fp16, widen to 8 consecutive channels per lane, two 16-B stores
-                    unsigned d[8];
-                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T, bool rowValid) {
-                        constexpr int K = decltype(kk)::value;
-                        if constexpr ((EXP & 8) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
-                        if constexpr (K >= 2 && K <= 14 && (K - 2) % 4 == 0)
-                        {
-                            constexpr int g = (K - 2) / 4;
-                            const f16x4 v = reluHalf4(acc, g);
-                            const uint2 u = *reinterpret_cast<const uint2*>(&v);
-                            d[2 * g] = u.x;
-                            d[2 * g + 1] = u.y;
-                        }
-                        if constexpr (K == 18 || K == 22)
-                        {
-                            // after the half-wave swaps a lane holds 8 consecutive channels
-                            constexpr int pair = (K - 18) / 4;
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-                            {
-                                const auto r = __builtin_amdgcn_permlane32_swap(d[4 * pair + k], d[4 * pair + 2 + k], false, false);
-                                d[4 * pair + k] = r[0];
-                                d[4 * pair + 2 + k] = r[1];
-                            }
-                        }
-                        if constexpr (K == 26)
-                        {
-                            // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
-                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                                a4f + (2 * row + py) * rowBytes, 0, (rowValid && !(EXP & 2)) ? int(rowBytes) : 0, 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T]), 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4], d[5], d[6], d[7]}, rs, int(laneSt[T] + 32u), 0, 0);
-                        }
-                    };
-                    if (ru < Y1)
-                    {
-                        const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
-                                  b2 = laneRd + slot5(ru + 1) * kA2Row;
-                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                            constexpr int K = decltype(kk)::value;
-                            constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
-                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
-                        };
-                        const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
-                        if (ru == Y0)
-                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
-                        // tile 0; finishes tile 1 of the previous row
-                        mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) {
-                                               finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
-                                               if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasUp, h);
-                                           });
-                        // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
-                        // first fragments come from row ru (slot b1)
-                        mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                           [&](auto kk) {
-                                               finish(kk, accA, ru, 0, true);
-                                               if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasUp, h);
-                                           });
-                    }
-                    else
-                        forEach<27>([&](auto kk) { finish(kk, accB, ru - 1, 1, true); });
-                }
+                const int b0 = laneRd + slot5(Y0 - 1) * kA2Row;
+                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+            }
+            for (int ru = Y0; ru < Y1; ++ru, ++t)
+            {
+                const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
+                          b2 = laneRd + slot5(ru + 1) * kA2Row;
+                // tile 0; finishes tile 1 of the previous row
+                mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) {
+                                       finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
+                                       if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasUp, h);
+                                   });
+                // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
+                // first fragments come from row ru (slot b1)
+                mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                   [&](auto kk) {
+                                       finish(kk, accA, ru, 0, true);
+                                       if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasUp, h);
+                                   });
                 stepBarrier();
             }
+            forEach<27>([&](auto kk) { finish(kk, accB, Y1 - 1, 1, true); });
+            stepBarrier();
+            for (++t; t <= tEnd; ++t) stepBarrier();
         }
         else if (role == 1)
         {
-            // ---- conv3, outputs 32 * (wave - 4) ..: row r3 = t - 5, rows Y0-1 .. Y1
+            // ---- conv3, outputs 32 * (wave - 4) ..: row r3 at step r3 + 5, rows Y0-1 .. Y1, and one more
+            // step to finish the last tile
             const int nt = wave - 4;
             const int laneRd = kA2Off + px * kA2Stride + h * 16;
             const int laneWr = kA3Off + px * kA2Stride + nt * 64 + h * 8;
             bool colInside[2];
 #pragma unroll
             for (int T = 0; T < 2; ++T) colInside[T] = X0 - 1 + T * 32 + px >= 0 && X0 - 1 + T * 32 + px < p.width;
+            f16x4 v;
+            const auto finish = [&](auto kk, const f32x16& acc, int row, int T) {
+                constexpr int K = decltype(kk)::value;
+                if constexpr ((EXP & 4) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
+                if constexpr (K >= 2 && K <= 30 && (K - 2) % 8 == 0)
+                {
+                    const bool inside = colInside[T] && row >= 0 && row < p.height;
+                    v = reluHalf4(acc, (K - 2) / 8);
+                    v = inside ? v : f16x4{0, 0, 0, 0};
+                }
+                if constexpr (K >= 6 && K <= 30 && (K - 6) % 8 == 0)
+                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + ((K - 6) / 8) * 16) = v;
+            };
+            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                constexpr int K = decltype(kk)::value;
+                constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+                const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+            };
+            const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+
+            int t = t0;
+            for (; t < Y0 + 4; ++t) stepBarrier();
             f32x16 accA = biasAcc(smem, kBiasC3 + nt * 32, h), accB = accA;
             Frags pre;
-            for (int t = t0; t <= tEnd; ++t)
             {
-                const int r3 = t - 5;
-                if (r3 >= Y0 - 1 && r3 <= Y1 + 1)
-                {
-                    f16x4 v;
-                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T) {
-                        constexpr int K = decltype(kk)::value;
-                        if constexpr ((EXP & 4) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
-                        if constexpr (K >= 2 && K <= 30 && (K - 2) % 8 == 0)
-                        {
-                            const bool inside = colInside[T] && row >= 0 && row < p.height;
-                            v = reluHalf4(acc, (K - 2) / 8);
-                            v = inside ? v : f16x4{0, 0, 0, 0};
-                        }
-                        if constexpr (K >= 6 && K <= 30 && (K - 6) % 8 == 0)
-                            *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + ((K - 6) / 8) * 16) = v;
-                    };
-                    if (r3 <= Y1)
-                    {
-                        const int b0 = laneRd + slot5(r3 - 1) * kA2Row, b1 = laneRd + slot5(r3) * kA2Row,
-                                  b2 = laneRd + slot5(r3 + 1) * kA2Row;
-                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                            constexpr int K = decltype(kk)::value;
-                            constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
-                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
-                        };
-                        const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
-                        if (r3 == Y0 - 1)
-                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
-                        mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) {
-                                               finish(kk, accB, r3 - 1, 1);
-                                               if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasC3 + nt * 32, h);
-                                           });
-                        mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                           [&](auto kk) {
-                                               finish(kk, accA, r3, 0);
-                                               if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasC3 + nt * 32, h);
-                                           });
-                    }
-                    else
-                        forEach<31>([&](auto kk) { finish(kk, accB, r3 - 1, 1); });
-                }
+                const int b0 = laneRd + slot5(Y0 - 2) * kA2Row;
+                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+            }
+            for (int r3 = Y0 - 1; r3 <= Y1; ++r3, ++t)
+            {
+                const int b0 = laneRd + slot5(r3 - 1) * kA2Row, b1 = laneRd + slot5(r3) * kA2Row,
+                          b2 = laneRd + slot5(r3 + 1) * kA2Row;
+                mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) {
+                                       finish(kk, accB, r3 - 1, 1);
+                                       if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasC3 + nt * 32, h);
+                                   });
+                mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                   [&](auto kk) {
+                                       finish(kk, accA, r3, 0);
+                                       if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasC3 + nt * 32, h);
+                                   });
                 stepBarrier();
             }
+            forEach<31>([&](auto kk) { finish(kk, accB, Y1, 1); });
+            stepBarrier();
+            for (++t; t <= tEnd; ++t) stepBarrier();
         }
         else if (role == 2)
         {
-            // ---- conv2, all 64 outputs as four chains (tile, half of the outputs): row r2 = t - 2, rows Y0-2 .. Y1+1
+            // ---- conv2, all 64 outputs as four chains (tile, half of the outputs): row r2 at step r2 + 2,
+            // rows Y0-2 .. Y1+1, and one more step to finish the last chain
             const int laneRd = kA1Off + px * kA1Stride + h * 16;
             const int laneWr = kA2Off + px * kA2Stride + h * 8;
             bool colInside[2];
 #pragma unroll
             for (int T = 0; T < 2; ++T) colInside[T] = X0 - 2 + T * 32 + px >= 0 && X0 - 2 + T * 32 + px < p.width;
+            f16x4 v;
+            const auto finish = [&](auto kk, const f32x16& acc, int row, int T, int half) {
+                constexpr int K = decltype(kk)::value;
+                if constexpr ((EXP & 4) != 0) { if constexpr (K == 1) asm volatile("" ::"v"(acc)); return; }
+                if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
+                {
+                    const bool inside = colInside[T] && row >= 0 && row < p.height;
+                    v = reluHalf4(acc, (K - 1) / 4);
+                    v = inside ? v : f16x4{0, 0, 0, 0};
+                }
+                if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
+                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + half * 64 + ((K - 3) / 4) * 16) = v;
+            };
+            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
+                constexpr int K = decltype(kk)::value;
+                constexpr int i = K / 6, j = (K / 2) % 3, cc = K % 2;
+                const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
+                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA1Stride + j * kA1Stride + cc * 32);
+            };
+            const auto wLo = [&](auto kk) { return wreg[decltype(kk)::value]; };
+            const auto wHi = [&](auto kk) { return wreg[18 + decltype(kk)::value]; };
+
+            int t = t0;
+            for (; t < Y0; ++t) stepBarrier();
             f32x16 acc0 = biasAcc(smem, kBiasC2, h), acc1 = biasAcc(smem, kBiasC2 + 32, h);
             Frags pre;
-            for (int t = t0; t <= tEnd; ++t)
             {
-                const int r2 = t - 2;
-                if (r2 >= Y0 - 2 && r2 <= Y1 + 2)
-                {
-                    f16x4 v;
-                    const auto finish = [&](auto kk, const f32x16& acc, int row, int T, int half) {
-                        constexpr int K = decltype(kk)::value;
-                        if constexpr ((EXP & 4) != 0) { if constexpr (K == 1) asm volatile("" ::"v"(acc)); return; }
-                        if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
-                        {
-                            const bool inside = colInside[T] && row >= 0 && row < p.height;
-                            v = reluHalf4(acc, (K - 1) / 4);
-                            v = inside ? v : f16x4{0, 0, 0, 0};
-                        }
-                        if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
-                            *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + half * 64 + ((K - 3) / 4) * 16) = v;
-                    };
-                    if (r2 <= Y1 + 1)
-                    {
-                        const int b0 = laneRd + ((r2 - 1) & 3) * kA1Row, b1 = laneRd + (r2 & 3) * kA1Row,
-                                  b2 = laneRd + ((r2 + 1) & 3) * kA1Row;
-                        const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                            constexpr int K = decltype(kk)::value;
-                            constexpr int i = K / 6, j = (K / 2) % 3, cc = K % 2;
-                            const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                            return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA1Stride + j * kA1Stride + cc * 32);
-                        };
-                        const auto wLo = [&](auto kk) { return wreg[decltype(kk)::value]; };
-                        const auto wHi = [&](auto kk) { return wreg[18 + decltype(kk)::value]; };
-                        if (r2 == Y0 - 2)
-                            forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b1, b2); });
-                        // (tile 0, outputs 0-31); finishes (tile 1, outputs 32-63) of the previous row
-                        mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                           [&](auto kk) {
-                                               finish(kk, acc1, r2 - 1, 1, 1);
-                                               if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
-                                           });
-                        mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) {
-                                               finish(kk, acc0, r2, 0, 0);
-                                               if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
-                                           });
-                        mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) {
-                                               finish(kk, acc1, r2, 0, 1);
-                                               if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
-                                           });
-                        mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                           [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                           [&](auto kk) {
-                                               finish(kk, acc0, r2, 1, 0);
-                                               if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
-                                           });
-                    }
-                    else
-                        forEach<16>([&](auto kk) { finish(kk, acc1, r2 - 1, 1, 1); });
-                }
+                const int b0 = laneRd + ((Y0 - 3) & 3) * kA1Row;
+                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+            }
+            for (int r2 = Y0 - 2; r2 <= Y1 + 1; ++r2, ++t)
+            {
+                const int b0 = laneRd + ((r2 - 1) & 3) * kA1Row, b1 = laneRd + (r2 & 3) * kA1Row,
+                          b2 = laneRd + ((r2 + 1) & 3) * kA1Row;
+                // (tile 0, outputs 0-31); finishes (tile 1, outputs 32-63) of the previous row
+                mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                   [&](auto kk) {
+                                       finish(kk, acc1, r2 - 1, 1, 1);
+                                       if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
+                                   });
+                mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) {
+                                       finish(kk, acc0, r2, 0, 0);
+                                       if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
+                                   });
+                mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) {
+                                       finish(kk, acc1, r2, 0, 1);
+                                       if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
+                                   });
+                mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
+                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
+                                   [&](auto kk) {
+                                       finish(kk, acc0, r2, 1, 0);
+                                       if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
+                                   });
                 stepBarrier();
             }
+            forEach<16>([&](auto kk) { finish(kk, acc1, Y1 + 1, 1, 1); });
+            stepBarrier();
+            for (++t; t <= tEnd; ++t) stepBarrier();
         }
         else
         {
@@ -537,6 +539,8 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     // a row of a4 must be addressable with a 32-bit byte offset
     if (long(l.a4.pitch) * 64 >= (1L << 31)) return hipErrorInvalidValue;
 
+    const char* envPrio = getenv("SRX_LR_PRIO");
+    p.prioMask = envPrio ? atoi(envPrio) : 14;
     const char* env = getenv("SRX_EXP_LR");
     const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);

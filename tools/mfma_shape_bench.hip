@@ -59,6 +59,50 @@ __global__ __launch_bounds__(256, 2) void bench(const f16x8* wsrc, const f16* ac
 #pragma unroll
         for (int r = 0; r < 16; ++r) result += acc[r];
     }
+    else if constexpr (SHAPE == 2)
+    {
+        // one activation fragment feeds three MFMAs (three output rows in flight): a third of the LDS reads
+        const int px = lane & 31, h = lane >> 5;
+        const int base = px * 144 + h * 16;
+        f32x16 acc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+        for (int it = 0; it < kIters; ++it)
+        {
+            const int off = base + (it & 7) * 4608;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+            {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(smem + off + (k / 4) * 144 + (k % 4) * 32);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[3 * k + a], b, acc[a], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it % 3][r] *= 0.001f;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) result += acc[a][r];
+    }
+    else if constexpr (SHAPE == 3)
+    {
+        // operands in registers: no LDS reads at all
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int it = 0; it < kIters; ++it)
+        {
+#pragma unroll
+            for (int k = 0; k < 36; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[k], w[(k + 7) % 36], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= 0.001f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) result += acc[r];
+    }
     else
     {
         const int p16 = lane & 15, q = lane >> 4;
@@ -134,6 +178,8 @@ int main()
     {
         run<0>("32x32x16", w, act, out, clock, blocks);
         run<1>("16x16x32", w, act, out, clock, blocks);
+        run<2>("32x32 r/3", w, act, out, clock, blocks);
+        run<3>("32x32 reg", w, act, out, clock, blocks);
     }
     return 0;
 }
