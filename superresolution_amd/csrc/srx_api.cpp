@@ -65,7 +65,7 @@ struct srx_ctx
     srx::FoldedWeights folded;
     uint16_t* wpk[srx::kNumConvLayers] = {};
     float* bias[srx::kNumConvLayers] = {};
-    uint16_t* wpk6Rows16 = nullptr;          // conv6 as 16x16x32 fragments (fused kernel)
+    uint16_t* wpk6Rows16 = nullptr;          // conv6 as row-streaming 16x16x32 fragments (fused kernel)
     uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
     float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
@@ -126,7 +126,7 @@ srx_status uploadWeights(srx_ctx* c)
         c->bias[l] = static_cast<float*>(d);
     }
     {
-        const std::vector<uint16_t> packed = PackConv3x3Rows16(c->folded.filter[6], 3, 32);
+        const std::vector<uint16_t> packed = PackConv6Rotating(c->folded.filter[6]);
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));

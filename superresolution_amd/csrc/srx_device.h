@@ -65,8 +65,7 @@ __device__ __forceinline__ f16x4 to_half4(float a, float b, float c, float d)
 // float -> R8G8B8A8_UNORM channel: NaN -> 0, clamp, scale, +0.5, drop fraction.
 __device__ __forceinline__ unsigned unorm8(float v)
 {
-    v = (v == v) ? v : 0.0f;
-    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    v = fminf(fmaxf(v, 0.0f), 1.0f);   // fmaxf returns its other operand for a NaN: NaN -> 0
     return (unsigned)(v * 255.0f + 0.5f);
 }
 

@@ -6,15 +6,24 @@
 // neither intermediate touches HBM and no row is computed twice vertically.  One
 // LDS barrier separates steps.  Wave w accumulates, per step, its 32-pixel half
 // (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) with 18
-// v_mfma_f32_32x32x16_f16, and its 16-pixel quarter of one row of conv6 with 9
-// v_mfma_f32_16x16x32_f16 (3 outputs padded to 16): every wave issues the same work.
+// v_mfma_f32_32x32x16_f16, and its 16-pixel quarter of conv6 with 3
+// v_mfma_f32_16x16x32_f16: every wave issues the same work.
+//
+// conv6 (32 -> 3 channels) streams input rows.  The 16 output rows of its MFMA are four
+// groups of (R, G, B, 0); group g accumulates the output row y with y mod 4 == g.  The
+// newest row R of conv5's output adds filter row 2 to output row R-1, filter row 1 to R
+// and filter row 0 to R+1 in ONE MFMA per horizontal tap (filter fragments per R mod 4:
+// PackConv6Rotating), so conv6 costs 3 MFMAs per step instead of 9 and reads each
+// activation fragment once.  A finished row is moved to a holding register and its group
+// cleared; every fourth step all 64 lanes convert and store a block of four rows.
 //
 // Software pipeline: what step t accumulates is converted and stored by step t+1,
 // a few VALU instructions in each gap between that step's MFMAs, so the epilogue
 // runs under the matrix pipe instead of after it.  Rows per step t:
-//     accumulate: conv4 row t      conv5 row t-3     conv6 row t-6
-//     finish:     conv4 row t-1    conv5 row t-4     conv6 row t-7
-// The loop is unrolled by four so every ring slot is a compile-time constant.
+//     accumulate: conv4 row t      conv5 row t-3     conv6 input row t-5
+//     finish:     conv4 row t-1    conv5 row t-4     conv6 output row t-7 -> holding register
+// The loop is unrolled by four so every ring slot and conv6 group is a compile-time
+// constant; segments start at multiples of four rows.
 //
 // Column bookkeeping for a strip whose first output column is X0:
 //   conv6 pixel i   = column X0 + i      (60 of 64 kept), reads a6 index i..i+2
@@ -47,6 +56,8 @@ constexpr int kHrA4 = 0;
 constexpr int kHrA5 = 4 * kHrRow32;
 constexpr int kHrA6 = 8 * kHrRow32;
 constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 67584
+constexpr int kAhead = 6;                             // LDS reads in flight ahead of their MFMA
+constexpr int kMfmas = 21;                            // per step: 18 (conv4 or conv5) + 3 (conv6)
 
 struct HrParams
 {
@@ -64,8 +75,9 @@ struct HrParams
 
 template <int N>
 using IC = std::integral_constant<int, N>;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// EXP: 0 = as designed; 1 = no scheduling pins (compiler order); 2 = no static priority.
+// EXP: 1 = no scheduling pins (compiler order); 2 = no static priority; 16 = no step barrier (timing only).
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 {
@@ -79,18 +91,18 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int L = wave >> 1, ti = wave & 1;
 
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
-    f16x8 wmain[18], w6[9];
+    f16x8 wmain[18], w6[12];
     {
         const f16x8* src = L ? p.wpk5 : p.wpk4;
 #pragma unroll
         for (int s = 0; s < 18; ++s) wmain[s] = src[s * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) w6[s] = p.wpk6[s * 64 + lane];
+        for (int s = 0; s < 12; ++s) w6[s] = p.wpk6[s * 64 + lane];
         // make the loads land here, not behind vmcnt waits inside the step loop
 #pragma unroll
         for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(wmain[s]));
 #pragma unroll
-        for (int s = 0; s < 9; ++s) asm volatile("" ::"v"(w6[s]));
+        for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(w6[s]));
     }
     f32x16 bias;
     {
@@ -133,6 +145,12 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int ldOff = kHrA4 + (tid >> 2) * kHrStride32 + (tid & 3) * 16;
     const int ldPixX = min(64 + (lane >> 2), kHrRowPix - 1);
     const int ldOffX = kHrA4 + ldPixX * kHrStride32 + (lane & 3) * 16;
+    const int ldSrc = (tid >> 2) * 64 + (tid & 3) * 16;         // byte offsets within an a4 row
+    const int ldSrcX = ldPixX * 64 + (lane & 3) * 16;
+    // conv6: lane group q holds the output row y with y mod 4 == q
+    bool qIs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qIs[g] = q == g;
 
     const int perFrame = p.strips * p.segs;
     for (TileWalk tw(p.numItems); tw.valid(); tw.next())
@@ -141,25 +159,32 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         const int rem = tw.cur - f * perFrame;
         const int seg = rem / p.strips;
         const int X0 = (rem - seg * p.strips) * kHrStrip;
-        const int Y0 = seg * p.segRows;
+        const int Y0 = seg * p.segRows;                       // a multiple of 4
         const int Y1 = min(p.height2, Y0 + p.segRows);
         const int t0 = Y0 - 2;
+        const int tLast = ((Y1 - 1) & ~3) + 10;               // the step that stores the last block of four rows
 
         const long rowBytes = long(p.a4.pitch) * 64;
-        const char* a4f = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + (long(X0) - 3) * 32);
-        // per-lane pointers to this lane's chunk of the NEXT row to fetch
-        const char* ldPtr = a4f + (tid >> 2) * 64 + (tid & 3) * 16 + (Y0 - 3) * rowBytes;
-        const char* ldPtrX = a4f + ldPixX * 64 + (lane & 3) * 16 + (Y0 - 3) * rowBytes;
+        // the a4 row to fetch next (uniform): one buffer descriptor per row, lanes add their chunk offset
+        const char* rowPtr = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + (long(X0) - 3) * 32) + (Y0 - 3) * rowBytes;
+        const auto loadRow = [&](int voff) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rowPtr), 0, kHrRowPix * 64, 0x00020000);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            return uint4{v[0], v[1], v[2], v[3]};
+        };
 
+        // output rows at or beyond Y1 fall outside this descriptor and are dropped
         const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
-            p.image + f * p.imageFrame, 0, int(p.imageFrame), 0x00020000);
+            p.image + f * p.imageFrame, 0, int(long(Y1) * p.imagePitch), 0x00020000);
+        const __amdgpu_buffer_rsrc_t inputRsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(p.input) + f * p.inputFrame, 0, int(p.inputFrame), 0x00020000);
 
-        // conv6: this lane's output column, whether it owns an output pixel, its byte offset in a row
+        // conv6: lane (p16, q) finishes the pixel (row 4B + q, column col6) of a block of rows 4B .. 4B+3
         const int col6 = X0 + wave * 16 + p16;
-        const bool laneOwns = q == 0 && wave * 16 + p16 < kHrStrip && col6 < p.width2;
-        const unsigned col6Bytes = unsigned(col6) * 4u;
-        // the residual term: NN2x(input) at this lane's conv6 pixel (clamped: masked lanes load a valid pixel)
-        const uint8_t* x0f = p.input + f * p.inputFrame + long(min(col6, p.width2 - 1) >> 1) * 4;
+        const bool laneOwns = wave * 16 + p16 < kHrStrip && col6 < p.width2;
+        const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * 4u;
+        // the residual term: NN2x(input) at that pixel = input pixel (2B + (q >> 1), col6 >> 1)
+        const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * 4u;
         // conv4 / conv5: is this lane's column inside the image?
         const bool colInside = X0 + colOff >= 0 && X0 + colOff < p.width2;
 
@@ -169,84 +194,57 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         for (int rr = 0; rr < 3; ++rr)
         {
             const int slot = (rr - 1) & 3;       // row t0 - 1 + rr
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOff) = *reinterpret_cast<const uint4*>(ldPtr);
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOffX) = *reinterpret_cast<const uint4*>(ldPtrX);
-            ldPtr += rowBytes;
-            ldPtrX += rowBytes;
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOff) = loadRow(ldSrc);
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOffX) = loadRow(ldSrcX);
+            rowPtr += rowBytes;
         }
         // Rows in flight in registers: step t issues the load of row t+3 into one register set and
         // parks the other (row t+2, loaded during step t-1), so a load has a whole step to land.
-        uint4 rowA = *reinterpret_cast<const uint4*>(ldPtr), rowB = rowA;
-        uint4 rowAX = *reinterpret_cast<const uint4*>(ldPtrX), rowBX = rowAX;
-        ldPtr += rowBytes;
-        ldPtrX += rowBytes;
-        // the residual term is fetched one step early and stays raw until the step that uses it, so its
-        // latency never sits in front of the MFMAs
-        const auto loadX0 = [&](int row2x) {
-            return *reinterpret_cast<const unsigned*>(x0f + long(min(max(row2x, 0), p.height2 - 1) >> 1) * p.inputPitch);
-        };
-        // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
-        const auto toTensor = [](unsigned v) {
-            constexpr float k = 1.0f / 255.0f;
-            return to_half4(float(v & 0xff) * k, float((v >> 8) & 0xff) * k, float((v >> 16) & 0xff) * k, 0.0f);
-        };
-        unsigned xinA = loadX0(t0 - 7), xinB = xinA;
+        uint4 rowA = loadRow(ldSrc), rowB = rowA;
+        uint4 rowAX = loadRow(ldSrcX), rowBX = rowAX;
+        rowPtr += rowBytes;
+        unsigned xraw = 0;                        // raw input pixel of the next block to store
         f32x16 accA, accB;
-        f32x4 acc6A = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc6B = acc6A;
+        f32x4 acc6 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float hold0 = 0.0f, hold1 = 0.0f, hold2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.0f;
         __syncthreads();
 
         // One step.  PH = (t - t0) & 3.
         const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
-                              const unsigned& xinRaw, unsigned& xinNext, const f32x16& accPrev, f32x16& acc,
-                              const f32x4& acc6Prev, f32x4& acc6) {
+                              const f32x16& accPrev, f32x16& acc) {
             constexpr int PH = decltype(phase)::value;
-            constexpr int kAhead = ((EXP >> 8) & 3) == 0 ? 6 : ((EXP >> 8) & 3) == 1 ? 3 : ((EXP >> 8) & 3) == 2 ? 10 : 14;
-            // ---- global loads: row t+3 (last needed row is Y1+2: stop advancing there) and the
-            // residual term of the row conv6 finishes NEXT step
-            if ((EXP & 32) == 0)
-            {
-                load = *reinterpret_cast<const uint4*>(ldPtr);
-                loadX = *reinterpret_cast<const uint4*>(ldPtrX);
-            }
-            const long adv = (t + 3 < Y1 + 2) ? rowBytes : 0;
-            ldPtr += adv;
-            ldPtrX += adv;
-            xinNext = loadX0(t - 6);
+            // ---- global loads: row t+3 (the last needed row is Y1+2: stop advancing there)
+            load = loadRow(ldSrc);
+            loadX = loadRow(ldSrcX);
+            rowPtr += (t + 3 < Y1 + 2) ? rowBytes : 0;
+            // the block of rows stored three steps from now starts at row t - 7 (phase 1 only)
+            if constexpr (PH == 1)
+                xraw = __builtin_amdgcn_raw_buffer_load_b32(inputRsrc, int(laneX0 + unsigned((t - 7) >> 1) * unsigned(p.inputPitch)), 0, 0);
 
             // ---- row bookkeeping of what this step finishes
             const int rowDone = t - 1 - lag;                         // conv4 / conv5 row being finished
             const bool rowInside = rowDone >= 0 && rowDone < p.height2;
             const bool inside = rowInside & colInside;
-            const int ro = t - 7;                                    // conv6 row being finished
-            const bool owns = laneOwns & (ro >= Y0) & (ro < Y1);
-            const unsigned outOff = owns ? unsigned(ro) * unsigned(p.imagePitch) + col6Bytes : 0xffffffffu;
 
             // ---- LDS addresses of this step
             const char* in0 = smem + inSlot[(PH + 3) & 3] + inLane;  // rows rc-1, rc, rc+1 of the input ring
             const char* in1 = smem + inSlot[PH] + inLane;
             const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;
-            const char* c60 = smem + ((PH + 1) & 3) * kHrRow6 + in6Lane;   // rows t-7, t-6, t-5 of a6
-            const char* c61 = smem + ((PH + 2) & 3) * kHrRow6 + in6Lane;
-            const char* c62 = smem + ((PH + 3) & 3) * kHrRow6 + in6Lane;
+            const char* c6 = smem + ((PH + 3) & 3) * kHrRow6 + in6Lane;    // row t-5 of a6
             char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;   // row rc-1 of the output ring
 
             const auto readFrag = [&](auto kk) -> f16x8 {
                 constexpr int K = decltype(kk)::value;
-                if constexpr ((EXP & 4) != 0) { f16x8 x = wmain[K % 18]; asm volatile("" : "+v"(x)); return x; }
-                else if constexpr (K < 18)
+                if constexpr (K < 18)
                 {
                     constexpr int i = K / 6, j = (K % 6) / 2, cc = K % 2;
                     const char* b = i == 0 ? in0 : (i == 1 ? in1 : in2);
                     return *reinterpret_cast<const f16x8*>(b + j * kHrStride32 + cc * 32);
                 }
                 else
-                {
-                    constexpr int i = (K - 18) / 3, j = (K - 18) % 3;
-                    const char* b = i == 0 ? c60 : (i == 1 ? c61 : c62);
-                    return *reinterpret_cast<const f16x8*>(b + j * kHrStride6);
-                }
+                    return *reinterpret_cast<const f16x8*>(c6 + (K - 18) * kHrStride6);
             };
 
             // epilogue state carried between the pieces below
@@ -257,77 +255,91 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                 v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
                 return inside ? v : f16x4{0, 0, 0, 0};
             };
-            // Piece K of the previous step's epilogue, issued in the gap after MFMA K.
+            // Piece K of the previous steps' epilogue, issued in the gap after MFMA K.
             const auto piece = [&](auto kk) {
                 constexpr int K = decltype(kk)::value;
+                constexpr int g = (PH + 3) & 3;      // conv6 group of the output row t-7, finished last step
                 if constexpr (K == 0) v0 = reluHalf4(0);
                 if constexpr (K == 1) { *reinterpret_cast<f16x4*>(outDst) = v0; v1 = reluHalf4(1); }
                 if constexpr (K == 2) { *reinterpret_cast<f16x4*>(outDst + 16) = v1; v2 = reluHalf4(2); }
                 if constexpr (K == 3) { *reinterpret_cast<f16x4*>(outDst + 32) = v2; v3 = reluHalf4(3); }
-                if constexpr (K == 4) { *reinterpret_cast<f16x4*>(outDst + 48) = v3; xin = toTensor(xinRaw); }
-                // conv6: D rows 0..2 (lanes 0..15) are R, G, B of pixel wave*16 + p16
-                if constexpr (K == 5) res = to_half4(acc6Prev[0], acc6Prev[1], acc6Prev[2], 0.0f);
+                if constexpr (K == 4) *reinterpret_cast<f16x4*>(outDst + 48) = v3;
+                if constexpr (K == 5)
+                {
+                    hold0 = qIs[g] ? acc6[0] : hold0;
+                    hold1 = qIs[g] ? acc6[1] : hold1;
+                    hold2 = qIs[g] ? acc6[2] : hold2;
+                }
                 if constexpr (K == 6)
-                    sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
-                                   (float)res[2] + (float)xin[2], 0.0f);
-                if constexpr (K == 7) c0 = unorm8((float)sum[0]);
-                if constexpr (K == 8) c1 = unorm8((float)sum[1]);
-                if constexpr (K == 9) c2 = unorm8((float)sum[2]);
-                if constexpr (K == 10)
-                    // branch-free: lanes that own no pixel store beyond the descriptor's range, which
-                    // the hardware drops
-                    __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc,
-                                                          int(outOff), 0, 0);
+                {
+                    acc6[0] = qIs[g] ? 0.0f : acc6[0];
+                    acc6[1] = qIs[g] ? 0.0f : acc6[1];
+                    acc6[2] = qIs[g] ? 0.0f : acc6[2];
+                }
+                // every fourth step: the block of rows t-10 .. t-7 is complete in the holding registers;
+                // lane (p16, q) converts and stores pixel (row t-10+q, column col6)
+                if constexpr (PH == 0)
+                {
+                    if constexpr (K == 7)
+                    {
+                        // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
+                        constexpr float k = 1.0f / 255.0f;
+                        xin = to_half4(float(xraw & 0xff) * k, float((xraw >> 8) & 0xff) * k, float((xraw >> 16) & 0xff) * k, 0.0f);
+                    }
+                    if constexpr (K == 8) res = to_half4(hold0, hold1, hold2, 0.0f);
+                    if constexpr (K == 9)
+                        sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
+                                       (float)res[2] + (float)xin[2], 0.0f);
+                    if constexpr (K == 10) c0 = unorm8((float)sum[0]);
+                    if constexpr (K == 11) c1 = unorm8((float)sum[1]);
+                    if constexpr (K == 12) c2 = unorm8((float)sum[2]);
+                    if constexpr (K == 13)
+                    {
+                        // branch-free: lanes that own no pixel, and blocks above the segment, store at an
+                        // offset beyond the descriptor's range, which the hardware drops
+                        const int blk = t - 10;
+                        const bool ok = laneOwns & (blk >= Y0);
+                        const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
+                    }
+                }
             };
 
             // ---- the MFMA stream: reads run kAhead in front, one epilogue piece per gap
-            f16x8 bq[27];
-            const f32x4 zero4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            f16x8 bq[kMfmas];
+            constexpr int rho = (PH + 1) & 3;        // (t - 5) mod 4
             const auto body = [&](auto kk) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K + kAhead < 27)
-                {
-                    // EXP & 64: half the reads (timing experiment)
-                    if constexpr ((EXP & 64) != 0 && ((K + kAhead) & 1)) bq[K + kAhead] = bq[K + kAhead - 1];
-                    else bq[K + kAhead] = readFrag(IC<K + kAhead>{});
-                }
-                // the first MFMA of each chain takes the bias (or zero) as its C operand
+                if constexpr (K + kAhead < kMfmas) bq[K + kAhead] = readFrag(IC<K + kAhead>{});
+                // the first MFMA of the conv4 / conv5 chain takes the bias as its C operand
                 if constexpr (K == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[0], bq[0], bias, 0, 0, 0);
                 else if constexpr (K < 18) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[K], bq[K], acc, 0, 0, 0);
-                else if constexpr (K == 18) acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[0], bq[18], zero4, 0, 0, 0);
-                else acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[K - 18], bq[K], acc6, 0, 0, 0);
-                if constexpr ((EXP & 8) == 0 && !((EXP & 128) && K >= 5) && !((EXP & 1024) && K < 5)) piece(kk);
-                else if constexpr (K == 0) asm volatile("" ::"v"(accPrev), "v"(acc6Prev));
+                else acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + (K - 18)], bq[K], acc6, 0, 0, 0);
+                piece(kk);
                 if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             };
             bq[0] = readFrag(IC<0>{}); bq[1] = readFrag(IC<1>{}); bq[2] = readFrag(IC<2>{});
-            if constexpr (kAhead > 3) { bq[3] = readFrag(IC<3>{}); bq[4] = readFrag(IC<4>{}); bq[5] = readFrag(IC<5>{}); }
-            if constexpr (kAhead > 6) { bq[6] = readFrag(IC<6>{}); bq[7] = readFrag(IC<7>{}); bq[8] = readFrag(IC<8>{}); bq[9] = readFrag(IC<9>{}); }
-            if constexpr (kAhead > 10) { bq[10] = readFrag(IC<10>{}); bq[11] = readFrag(IC<11>{}); bq[12] = readFrag(IC<12>{}); bq[13] = readFrag(IC<13>{}); }
+            bq[3] = readFrag(IC<3>{}); bq[4] = readFrag(IC<4>{}); bq[5] = readFrag(IC<5>{});
             if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{}); body(IC<5>{});
             body(IC<6>{}); body(IC<7>{}); body(IC<8>{}); body(IC<9>{}); body(IC<10>{}); body(IC<11>{});
             body(IC<12>{}); body(IC<13>{}); body(IC<14>{}); body(IC<15>{}); body(IC<16>{}); body(IC<17>{});
-            body(IC<18>{}); body(IC<19>{}); body(IC<20>{}); body(IC<21>{}); body(IC<22>{}); body(IC<23>{});
-            body(IC<24>{}); body(IC<25>{}); body(IC<26>{});
+            body(IC<18>{}); body(IC<19>{}); body(IC<20>{});
 
             // ---- park row t+2
-            if ((EXP & 32) == 0)
-            {
-                *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
-                *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
-            }
+            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
+            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
             if ((EXP & 16) == 0) barrierLds();
         };
 
-        // steps t0 .. Y1+7 (conv6's last row Y1-1 is finished by step Y1+6), rounded up to a multiple
-        // of four; surplus steps touch only ring rows nothing reads and store nothing
-        for (int t = t0; t <= Y1 + 6; t += 4)
+        // steps t0 .. tLast + 3; the three steps after the last store touch only ring rows nothing
+        // reads and store nothing
+        for (int t = t0; t <= tLast; t += 4)
         {
-            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX, xinA, xinB, accA, accB, acc6A, acc6B);
-            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
-            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX, xinA, xinB, accA, accB, acc6A, acc6B);
-            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX, xinB, xinA, accB, accA, acc6B, acc6A);
+            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX, accA, accB);
+            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX, accB, accA);
+            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX, accA, accB);
+            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX, accB, accA);
         }
     }
     if (p.clock && tid == 0)
@@ -345,14 +357,15 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     if (width2 <= 0 || height2 <= 0 || batch <= 0 || numCUs <= 0) return pl;
     pl.strips = (width2 + kHrStrip - 1) / kHrStrip;
     // split the rows so that there are about two work items per CU (two workgroups share a CU); every
-    // segment re-computes 9 warm-up rows, so keep segments at least 32 rows tall
+    // segment re-computes about 12 warm-up rows, so keep segments at least 32 rows tall; segments
+    // start at multiples of four rows (conv6 stores blocks of four)
     int segs = (2 * numCUs + pl.strips * batch - 1) / (pl.strips * batch);
     const int maxSegs = height2 / 32 > 1 ? height2 / 32 : 1;
     segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
-    pl.segRows = (height2 + segs - 1) / segs;
+    pl.segRows = ((height2 + segs - 1) / segs + 3) & ~3;
     pl.segs = (height2 + pl.segRows - 1) / pl.segRows;
     pl.items = pl.strips * pl.segs * batch;
-    pl.steps = pl.segRows + 12;
+    pl.steps = pl.segRows + 16;
     const int slots = gridFor(pl.items, numCUs);
     pl.rounds = (pl.items + slots - 1) / slots;
     return pl;
@@ -381,11 +394,12 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.segRows = plan.segRows;
     p.numItems = plan.items;
     if (p.numItems <= 0) return hipErrorInvalidValue;
+    // one input and one output frame must be addressable with a 32-bit byte offset
+    if (p.imageFrame >= (1L << 31) || p.inputFrame >= (1L << 31)) return hipErrorInvalidValue;
 
     const char* env = getenv("SRX_EXP");
     const int exp = env ? atoi(env) : 0;
-    const char* envCu = getenv("SRX_HR_PER_CU");
-    const dim3 grid(gridFor(p.numItems, numCUs, envCu ? atoi(envCu) : 2)), block(kThreads);
+    const dim3 grid(gridFor(p.numItems, numCUs)), block(kThreads);
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
 #define SRX_HR_CASE(E)                                                                                       \
@@ -405,9 +419,7 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.clock = clockProbeBuffer(probe, int(grid.x));
     switch (exp)
     {
-        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(4) SRX_HR_CASE(8) SRX_HR_CASE(16) SRX_HR_CASE(32)
-        SRX_HR_CASE(12) SRX_HR_CASE(28) SRX_HR_CASE(60) SRX_HR_CASE(56) SRX_HR_CASE(48)
-        SRX_HR_CASE(128) SRX_HR_CASE(1024) SRX_HR_CASE(36) SRX_HR_CASE(64) SRX_HR_CASE(256) SRX_HR_CASE(512) SRX_HR_CASE(768) SRX_HR_CASE(24) SRX_HR_CASE(40)
+        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(16)
     default:
         SRX_HR_CASE(0)
     }

@@ -294,6 +294,29 @@ std::vector<uint16_t> PackConv3x3Rows16(const std::vector<uint16_t>& oihw, int c
     return out;
 }
 
+std::vector<uint16_t> PackConv6Rotating(const std::vector<uint16_t>& oihw)
+{
+    // [rho][j][lane][8]: A row 4 * g + c (lane & 15), k = 8 * (lane >> 4) + jj
+    std::vector<uint16_t> out(size_t(4) * 3 * 64 * 8, 0);
+    for (int rho = 0; rho < 4; ++rho)
+        for (int j = 0; j < 3; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+            {
+                const int row = lane & 15, q = lane >> 4;
+                const int g = row >> 2, c = row & 3;
+                if (c >= 3) continue;
+                // the filter row i that input row R (R mod 4 == rho) contributes to output row group g
+                int i = -1;
+                if (g == ((rho + 3) & 3)) i = 2;        // output row R - 1
+                else if (g == rho) i = 1;               // output row R
+                else if (g == ((rho + 1) & 3)) i = 0;   // output row R + 1
+                if (i < 0) continue;                    // group of row R + 2: not touched by this input row
+                for (int jj = 0; jj < 8; ++jj)
+                    out[((size_t(rho) * 3 + j) * 64 + lane) * 8 + jj] = oihw[(size_t(c) * 32 + 8 * q + jj) * 9 + i * 3 + j];
+            }
+    return out;
+}
+
 std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw)
 {
     constexpr int ksteps = 7;

@@ -94,6 +94,12 @@ std::vector<uint16_t> PackConv3x3(const std::vector<uint16_t>& oihw, int cout, i
 // A[row = l & 15][k = 8 * (l >> 4) + j]; one kstep per tap covers 32 input channels;
 // output channels are padded with zero rows to 16.  Layout [tap][lane][8].
 std::vector<uint16_t> PackConv3x3Rows16(const std::vector<uint16_t>& oihw, int cout, int cin /* == 32 */);
+// conv6 (3x3, 32 -> 3, no bias) for a kernel that streams input rows: fragments of
+// v_mfma_f32_16x16x32_f16 whose 16 output rows are four groups of (R, G, B, 0), group g holding the
+// output row y with y mod 4 == g.  Input row R (rho = R mod 4) contributes filter row 2 to output row
+// R-1, filter row 1 to R and filter row 0 to R+1; the fourth group's rows are zero.  One K-step per
+// horizontal tap j covers the 32 input channels.  Layout [rho][j][lane][8]; oihw is [3,32,3,3].
+std::vector<uint16_t> PackConv6Rotating(const std::vector<uint16_t>& oihw);
 // conv1 (5x5 on RGB0 pixels of 4 halfs): 7 ksteps of 4 taps x 4 channels,
 // k = 4 * (tap - 4*kstep) + channel; taps 25..27 and channel 3 are zero.
 std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw /*[32,3,5,5]*/);
