@@ -77,7 +77,8 @@ template <int N>
 using IC = std::integral_constant<int, N>;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// EXP: 1 = no scheduling pins (compiler order); 2 = no static priority; 16 = no step barrier (timing only).
+// EXP: 1 = pin every epilogue piece to its MFMA gap (default: the compiler places them, which measured
+// 2 % faster); 2 = no static priority; 16 = no step barrier (timing only).
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 {
@@ -316,11 +317,11 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                 else if constexpr (K < 18) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[K], bq[K], acc, 0, 0, 0);
                 else acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + (K - 18)], bq[K], acc6, 0, 0, 0);
                 piece(kk);
-                if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                if ((EXP & 1) != 0) __builtin_amdgcn_sched_barrier(0);
             };
             bq[0] = readFrag(IC<0>{}); bq[1] = readFrag(IC<1>{}); bq[2] = readFrag(IC<2>{});
             bq[3] = readFrag(IC<3>{}); bq[4] = readFrag(IC<4>{}); bq[5] = readFrag(IC<5>{});
-            if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            if ((EXP & 1) != 0) __builtin_amdgcn_sched_barrier(0);
             body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{}); body(IC<5>{});
             body(IC<6>{}); body(IC<7>{}); body(IC<8>{}); body(IC<9>{}); body(IC<10>{}); body(IC<11>{});
             body(IC<12>{}); body(IC<13>{}); body(IC<14>{}); body(IC<15>{}); body(IC<16>{}); body(IC<17>{});
