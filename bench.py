@@ -66,6 +66,31 @@ def cpu_baseline():
                       f"(reference graph, direct conv_up1), OpenMP {threads} threads, {dt:.2f} s"}
 
 
+def pcie_inclusive(S, frames, device):
+    """Frames that start and end in (pinned) host memory, through the frame pipe: 3 slots of 8 frames
+    in flight.  Reported beside the headline number, never as `value`."""
+    per_slot, slots, rounds = 8, 3, 8
+    with S.SuperResolutionContext(W, H, batch=per_slot * slots, device=device) as ctx, S.FramePipe(ctx, per_slot) as pipe:
+        for s in range(slots):
+            buf = pipe.input(s)
+            for k in range(per_slot):
+                buf[k] = frames[k % len(frames)]
+        for s in range(slots):                       # fill the pipe (untimed)
+            pipe.submit(s)
+        t0 = time.perf_counter()
+        for r in range(rounds):
+            for s in range(slots):
+                pipe.wait(s)                         # a real caller consumes / refills the pinned buffers here
+                pipe.submit(s)
+        for s in range(slots):
+            pipe.wait(s)
+        dt = time.perf_counter() - t0
+    n = rounds * slots * per_slot
+    return {"frames_per_s": round(n / dt, 1), "output_megapixels_per_s": round(n / dt * OUT_MP, 1),
+            "note": f"{n} frames host->GPU->host through srx_pipe_* (pinned buffers, {slots} slots x {per_slot} frames, "
+                    "upload / compute / download on three streams); 8.3 MB in + 33.2 MB out per frame over PCIe"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-reps", type=int, default=20)
+    ap.add_argument("--no-pcie-leg", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +208,8 @@ def main():
                                  "load: a bare LDS-fed MFMA loop of the same shape measures 1.58 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
+        if world == 1 and not args.no_pcie_leg:
+            out["pcie_inclusive"] = pcie_inclusive(S, distinct, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

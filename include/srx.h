@@ -117,6 +117,12 @@ srx_status srx_tensor_to_image(srx_ctx* ctx, uint32_t frame, uint8_t* host_rgba,
  * SuperResolutionX.cpp:347-353). */
 srx_status srx_upscale(srx_ctx* ctx, void* stream);
 
+/* The same for frames [first, first + count) only: lets a caller keep several
+ * groups of frames in flight on different streams' copies while one stream
+ * computes (the ctx's activation workspace is shared, so calls must be ordered
+ * on ONE compute stream).  Not available with SRX_FLAG_KEEP_TENSORS. */
+srx_status srx_upscale_frames(srx_ctx* ctx, uint32_t first, uint32_t count, void* stream);
+
 /* WaitForGpu (SuperResolutionX.cpp:374-385). */
 srx_status srx_sync(srx_ctx* ctx, void* stream);
 
@@ -153,6 +159,35 @@ srx_status  srx_launch_stage(srx_ctx* ctx, int32_t i, void* stream);
 /* Frames one srx_launch_stage() of a convolution stage covers (the activation
  * workspace holds this many frames; srx_process walks the batch in such passes). */
 uint32_t    srx_frames_per_launch(const srx_ctx* ctx);
+
+/*
+ * Frame pipe: the counterpart of the reference's frames in flight
+ * (FrameCount = 3 back buffers with one fence value each, SuperResolutionX.h:49,
+ * :69-72; MoveToNextFrame, SuperResolutionX.cpp:388-405) for a headless stream of
+ * frames that starts and ends in host memory.  The ctx's `batch` frames are
+ * divided into slots of `frames_per_slot` frames (at least two slots).  Each
+ * slot owns pinned host buffers for its input and output frames; a submitted
+ * slot is copied to the GPU, upscaled and copied back on three HIP streams the
+ * pipe owns, so the copies of one slot overlap the kernels of another.
+ *
+ *   srx_pipe_input  : the slot's pinned RGBA8 input frames (tightly packed:
+ *                     pitch = in_w*4, frame stride = pitch*in_h) for the caller to fill
+ *   srx_pipe_submit : enqueue upload + upscale + download of the slot; returns at once
+ *   srx_pipe_wait   : block until the slot's output frames are in its pinned
+ *                     output buffer (pitch = out_w*4) and return it; the buffers of
+ *                     a slot may be touched again only after this returned
+ * A pipe is driven by one host thread; while it exists the ctx must not be
+ * used through other entry points.
+ */
+typedef struct srx_pipe srx_pipe;
+srx_status srx_pipe_create(srx_ctx* ctx, uint32_t frames_per_slot, srx_pipe** out);
+srx_status srx_pipe_destroy(srx_pipe* pipe);
+uint32_t   srx_pipe_slots(const srx_pipe* pipe);
+srx_status srx_pipe_input(srx_pipe* pipe, uint32_t slot, uint8_t** host_rgba,
+                          size_t* pitch, size_t* frame_stride);
+srx_status srx_pipe_submit(srx_pipe* pipe, uint32_t slot);
+srx_status srx_pipe_wait(srx_pipe* pipe, uint32_t slot, const uint8_t** host_rgba_out,
+                         size_t* pitch, size_t* frame_stride);
 
 /* Message of the last failure on this thread (never NULL). */
 const char* srx_last_error(void);

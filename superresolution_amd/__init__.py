@@ -4,9 +4,9 @@ The compute lives in superresolution_amd/libsrx.so (HIP kernels for gfx950 +
 C ABI); this module only binds it with ctypes.  There is no CPU fallback: if the
 library is missing or the device is not a gfx950 GPU, calls raise.
 """
-from ._capi import (SrxError, SuperResolutionContext, lib, lib_path, ASSETS_DIR, default_weights_path,
+from ._capi import (SrxError, SuperResolutionContext, FramePipe, lib, lib_path, ASSETS_DIR, default_weights_path,
                     FLAG_KEEP_TENSORS, FLAG_VERBOSE_WEIGHTS, TENSOR_NAMES, build_library,
                     fold_weights, packed_weights)
 
-__all__ = ["SrxError", "SuperResolutionContext", "lib", "lib_path", "ASSETS_DIR", "default_weights_path",
+__all__ = ["SrxError", "SuperResolutionContext", "FramePipe", "lib", "lib_path", "ASSETS_DIR", "default_weights_path",
            "FLAG_KEEP_TENSORS", "FLAG_VERBOSE_WEIGHTS", "TENSOR_NAMES", "build_library", "fold_weights", "packed_weights"]

@@ -16,7 +16,9 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_upload_rgb8", "srx_input_device_ptr", "srx_output_device_ptr", "srx_image_to_tensor",
            "srx_process", "srx_tensor_to_image", "srx_upscale", "srx_sync", "srx_read_tensor",
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
-           "srx_launch_stage", "srx_frames_per_launch", "srx_last_error"]
+           "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
+           "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
+           "srx_pipe_wait"]
 
 
 class SrxError(RuntimeError):
@@ -80,10 +82,18 @@ def lib():
     L.srx_launch_stage.argtypes = [vp, i32, vp]
     L.srx_last_error.restype = C.c_char_p
     L.srx_frames_per_launch.argtypes = [vp]
+    L.srx_upscale_frames.argtypes = [vp, u32, u32, vp]
+    L.srx_pipe_create.argtypes = [vp, u32, C.POINTER(vp)]
+    L.srx_pipe_destroy.argtypes = [vp]
+    L.srx_pipe_slots.argtypes = [vp]
+    L.srx_pipe_input.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.srx_pipe_submit.argtypes = [vp, u32]
+    L.srx_pipe_wait.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     for name in SYMBOLS:
-        if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch"):
+        if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch", "srx_pipe_slots"):
             getattr(L, name).restype = i32
     L.srx_frames_per_launch.restype = u32
+    L.srx_pipe_slots.restype = u32
     _lib = L
     return L
 
@@ -152,6 +162,9 @@ class SuperResolutionContext:
     def upscale(self, stream=None):
         _check(self._L.srx_upscale(self._h, stream))
 
+    def upscale_frames(self, first, count, stream=None):
+        _check(self._L.srx_upscale_frames(self._h, first, count, stream))
+
     def sync(self, stream=None):
         _check(self._L.srx_sync(self._h, stream))
 
@@ -188,6 +201,48 @@ class SuperResolutionContext:
         self.upload_rgba8(frame, rgba)
         self.upscale()
         return self.tensor_to_image(frame)
+
+
+class FramePipe:
+    """Frames in flight between host memory and one ctx: pinned buffers per slot, three streams."""
+
+    def __init__(self, ctx, frames_per_slot):
+        self._ctx, self._L, self._h = ctx, ctx._L, C.c_void_p()
+        _check(self._L.srx_pipe_create(ctx._h, frames_per_slot, C.byref(self._h)))
+        self.frames_per_slot = frames_per_slot
+        self.slots = int(self._L.srx_pipe_slots(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.srx_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def input(self, slot):
+        """The slot's pinned input frames as a writable uint8 array [frames_per_slot, H, W, 4]."""
+        ptr, pitch, stride = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._L.srx_pipe_input(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
+        n = self.frames_per_slot * stride.value
+        buf = (C.c_uint8 * n).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, self._ctx.height, self._ctx.width, 4)
+
+    def submit(self, slot):
+        _check(self._L.srx_pipe_submit(self._h, slot))
+
+    def wait(self, slot):
+        """Block until the slot is done; returns its pinned output frames [frames_per_slot, 2H, 2W, 4] (a view)."""
+        ptr, pitch, stride = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._L.srx_pipe_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
+        n = self.frames_per_slot * stride.value
+        buf = (C.c_uint8 * n).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, 4)
 
 
 def fold_weights(layer, weights_path=None):

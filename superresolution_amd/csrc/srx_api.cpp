@@ -477,6 +477,21 @@ srx_status srx_upscale(srx_ctx* c, void* stream)
     return srx_process(c, stream);
 }
 
+srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream)
+{
+    if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
+        return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
+    if (c->keep()) return fail(SRX_ERR_STATE, "srx_upscale_frames: not available with SRX_FLAG_KEEP_TENSORS (kept tensors are indexed by frame of the whole batch)");
+    SRX_HIP(hipSetDevice(c->device));
+    for (uint32_t f = first; f < first + count; f += c->chunk)
+    {
+        const uint32_t n = std::min(c->chunk, first + count - f);
+        for (size_t i = 0; i < c->stages.size(); ++i)
+            if (const srx_status s = launchStage(c, c->stages[i], f, n, static_cast<hipStream_t>(stream))) return s;
+    }
+    return SRX_OK;
+}
+
 srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t pitch, void* stream)
 {
     if (!validCtx(c) || frame >= c->batch) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: bad frame");
@@ -590,6 +605,133 @@ srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
     SRX_HIP(hipSetDevice(c->device));
     const uint32_t count = (c->stages[size_t(i)] == ST_PACK) ? c->batch : std::min(c->chunk, c->batch);
     return launchStage(c, c->stages[size_t(i)], 0, count, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------
+// Frame pipe: pinned staging buffers and three streams around srx_upscale_frames.
+// ---------------------------------------------------------------------------
+struct srx_pipe
+{
+    srx_ctx* ctx = nullptr;
+    uint32_t perSlot = 0, slots = 0;
+    size_t inPitch = 0, inFrame = 0, outPitch = 0, outFrame = 0;    // host layouts (tightly packed)
+    std::vector<uint8_t*> hostIn, hostOut;
+    hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+    std::vector<hipEvent_t> evUp, evComp, evDown;
+    std::vector<bool> submitted;
+};
+
+srx_status srx_pipe_destroy(srx_pipe* p)
+{
+    if (!p) return SRX_OK;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    for (hipStream_t st : {p->up, p->comp, p->down})
+        if (st) (void)hipStreamSynchronize(st);
+    for (uint8_t* h : p->hostIn) if (h) (void)hipHostFree(h);
+    for (uint8_t* h : p->hostOut) if (h) (void)hipHostFree(h);
+    for (auto* v : {&p->evUp, &p->evComp, &p->evDown})
+        for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {p->up, p->comp, p->down})
+        if (st) (void)hipStreamDestroy(st);
+    delete p;
+    return SRX_OK;
+}
+
+srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out)
+{
+    if (!out) return fail(SRX_ERR_INVALID, "srx_pipe_create: out is NULL");
+    *out = nullptr;
+    if (!validCtx(c) || framesPerSlot == 0 || c->batch / framesPerSlot < 2)
+        return fail(SRX_ERR_INVALID, "srx_pipe_create: the ctx's batch must hold at least two slots of frames_per_slot frames");
+    if (c->keep()) return fail(SRX_ERR_STATE, "srx_pipe_create: not available with SRX_FLAG_KEEP_TENSORS");
+    SRX_HIP(hipSetDevice(c->device));
+    srx_pipe* p = new srx_pipe;
+    p->ctx = c;
+    p->perSlot = framesPerSlot;
+    p->slots = c->batch / framesPerSlot;
+    p->inPitch = size_t(c->width) * 4;
+    p->inFrame = p->inPitch * c->height;
+    p->outPitch = size_t(c->width) * 8;
+    p->outFrame = p->outPitch * c->height * 2;
+    p->hostIn.assign(p->slots, nullptr);
+    p->hostOut.assign(p->slots, nullptr);
+    p->evUp.assign(p->slots, nullptr);
+    p->evComp.assign(p->slots, nullptr);
+    p->evDown.assign(p->slots, nullptr);
+    p->submitted.assign(p->slots, false);
+    const auto bail = [&](hipError_t e, const char* what) {
+        const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        srx_pipe_destroy(p);
+        return fail(e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_HIP, msg);
+    };
+    hipError_t e;
+    for (hipStream_t* st : {&p->up, &p->comp, &p->down})
+        if ((e = hipStreamCreateWithFlags(st, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreateWithFlags");
+    for (uint32_t s = 0; s < p->slots; ++s)
+    {
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&p->hostIn[s]), p->inFrame * framesPerSlot, hipHostMallocDefault)) != hipSuccess)
+            return bail(e, "hipHostMalloc(input)");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&p->hostOut[s]), p->outFrame * framesPerSlot, hipHostMallocDefault)) != hipSuccess)
+            return bail(e, "hipHostMalloc(output)");
+        for (hipEvent_t* ev : {&p->evUp[s], &p->evComp[s], &p->evDown[s]})
+            if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreateWithFlags");
+    }
+    *out = p;
+    return SRX_OK;
+}
+
+uint32_t srx_pipe_slots(const srx_pipe* p) { return p ? p->slots : 0; }
+
+srx_status srx_pipe_input(srx_pipe* p, uint32_t slot, uint8_t** host, size_t* pitch, size_t* frameStride)
+{
+    if (!p || slot >= p->slots || !host) return fail(SRX_ERR_INVALID, "srx_pipe_input: bad pipe, slot or pointer");
+    *host = p->hostIn[slot];
+    if (pitch) *pitch = p->inPitch;
+    if (frameStride) *frameStride = p->inFrame;
+    return SRX_OK;
+}
+
+srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot)
+{
+    if (!p || slot >= p->slots) return fail(SRX_ERR_INVALID, "srx_pipe_submit: bad pipe or slot");
+    srx_ctx* c = p->ctx;
+    SRX_HIP(hipSetDevice(c->device));
+    const uint32_t first = slot * p->perSlot;
+    // the slot's device input may still be read by its previous upscale, its device output by its
+    // previous download
+    if (p->submitted[slot])
+    {
+        SRX_HIP(hipStreamWaitEvent(p->up, p->evComp[slot], 0));
+        SRX_HIP(hipStreamWaitEvent(p->comp, p->evDown[slot], 0));
+    }
+    for (uint32_t f = 0; f < p->perSlot; ++f)
+        SRX_HIP(hipMemcpy2DAsync(c->input.base + size_t(first + f) * c->input.frame, size_t(c->input.pitch),
+                                 p->hostIn[slot] + f * p->inFrame, p->inPitch, p->inPitch, c->height,
+                                 hipMemcpyHostToDevice, p->up));
+    SRX_HIP(hipEventRecord(p->evUp[slot], p->up));
+    SRX_HIP(hipStreamWaitEvent(p->comp, p->evUp[slot], 0));
+    if (const srx_status s = srx_upscale_frames(c, first, p->perSlot, p->comp)) return s;
+    SRX_HIP(hipEventRecord(p->evComp[slot], p->comp));
+    SRX_HIP(hipStreamWaitEvent(p->down, p->evComp[slot], 0));
+    for (uint32_t f = 0; f < p->perSlot; ++f)
+        SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot] + f * p->outFrame, p->outPitch,
+                                 c->output.base + size_t(first + f) * c->output.frame, size_t(c->output.pitch),
+                                 p->outPitch, size_t(c->height) * 2, hipMemcpyDeviceToHost, p->down));
+    SRX_HIP(hipEventRecord(p->evDown[slot], p->down));
+    p->submitted[slot] = true;
+    return SRX_OK;
+}
+
+srx_status srx_pipe_wait(srx_pipe* p, uint32_t slot, const uint8_t** host, size_t* pitch, size_t* frameStride)
+{
+    if (!p || slot >= p->slots) return fail(SRX_ERR_INVALID, "srx_pipe_wait: bad pipe or slot");
+    if (!p->submitted[slot]) return fail(SRX_ERR_STATE, "srx_pipe_wait: the slot was never submitted");
+    SRX_HIP(hipSetDevice(p->ctx->device));
+    SRX_HIP(hipEventSynchronize(p->evDown[slot]));
+    if (host) *host = p->hostOut[slot];
+    if (pitch) *pitch = p->outPitch;
+    if (frameStride) *frameStride = p->outFrame;
+    return SRX_OK;
 }
 
 }  // extern "C"

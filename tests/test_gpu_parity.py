@@ -219,3 +219,53 @@ def test_invalid_arguments():
         assert len(ctx.stage_names()) == L.srx_num_stages(ctx._h)
     with S.SuperResolutionContext(16, 16, flags=S.FLAG_KEEP_TENSORS) as ctx:
         assert ctx.stage_names()[0] == "image_to_tensor" and len(ctx.stage_names()) == 8
+
+
+def test_full_hd_pass_of_eight_frames_matches_single_frames():
+    """At the benchmark size a pass holds eight frames and the strips run the full image height; a
+    lone frame is cut into row segments instead.  Both plans must give the same bytes."""
+    W, H = 1920, 1080
+    frames = [synthetic_rgba(W, H, 2000 + i) for i in range(2)]
+    with S.SuperResolutionContext(W, H) as one:
+        singles = [one.run(f) for f in frames]
+    with S.SuperResolutionContext(W, H, batch=8) as ctx:
+        assert ctx.frames_per_launch == 8
+        for i in range(8):
+            ctx.upload_rgba8(i, frames[i % 2])
+        ctx.upscale()
+        ctx.sync()
+        for i in (0, 1, 6, 7):
+            assert np.array_equal(ctx.tensor_to_image(i), singles[i % 2])
+
+
+def test_frame_pipe_matches_plain_upscale():
+    """The pinned-buffer frame pipe (three slots in flight, slots reused over three rounds) returns
+    the same bytes as upload + upscale + download of each frame."""
+    W, H, per_slot = 70, 45, 2
+    frames = [synthetic_rgba(W, H, 3000 + i) for i in range(18)]
+    with S.SuperResolutionContext(W, H) as one:
+        expect = [one.run(f) for f in frames]
+    with S.SuperResolutionContext(W, H, batch=6) as ctx, S.FramePipe(ctx, per_slot) as pipe:
+        assert pipe.slots == 3
+        groups = [frames[i:i + per_slot] for i in range(0, len(frames), per_slot)]
+        done = 0
+        for g, group in enumerate(groups):
+            slot = g % pipe.slots
+            if g >= pipe.slots:                      # the slot's previous result must be taken first
+                out = pipe.wait(slot)
+                for k in range(per_slot):
+                    assert np.array_equal(out[k], expect[(g - pipe.slots) * per_slot + k])
+                done += 1
+            buf = pipe.input(slot)
+            for k, f in enumerate(group):
+                buf[k] = f
+            pipe.submit(slot)
+        for g in range(len(groups) - pipe.slots, len(groups)):
+            out = pipe.wait(g % pipe.slots)
+            for k in range(per_slot):
+                assert np.array_equal(out[k], expect[g * per_slot + k])
+            done += 1
+        assert done == len(groups)
+    with S.SuperResolutionContext(W, H, batch=1) as ctx:
+        with pytest.raises(S.SrxError):
+            S.FramePipe(ctx, 1)                      # needs two slots
