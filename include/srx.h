@@ -41,7 +41,21 @@ enum {
     SRX_FLAG_KEEP_TENSORS = 1u << 0,
     /* Print "Number of weight tensors" / "Loaded tensor: ..." like
      * Content/LoadWeights.cpp:50,75 while parsing weights.bin. */
-    SRX_FLAG_VERBOSE_WEIGHTS = 1u << 1
+    SRX_FLAG_VERBOSE_WEIGHTS = 1u << 1,
+    /* Build the graph literally as SuperResolution::createResources does
+     * (Content/SuperResolution.cpp:172-275): every layer made by the generic
+     * layer factories, up1 materialised, conv_up1 as a direct 5x5 convolution.
+     * All tensors are kept (srx_read_tensor works).  Slow VALU kernels: a parity
+     * anchor, not the product path. */
+    SRX_FLAG_GENERIC_LAYERS = 1u << 2,
+    /* fp32 tensors and untruncated fp32 weights: the reference's mode when the
+     * device lacks fp16 (Content/SuperResolution.cpp:161-163).  Implies
+     * SRX_FLAG_GENERIC_LAYERS; srx_read_tensor then returns fp32. */
+    SRX_FLAG_FP32 = 1u << 3,
+    /* NHWC tensors and O,kh,kw,I filters inside the generic graph: the
+     * reference's TensorLayout::NHWC switch (Content/SuperResolution.cpp:155-159).
+     * Implies SRX_FLAG_GENERIC_LAYERS; srx_read_tensor still returns planar CHW. */
+    SRX_FLAG_NHWC = 1u << 4
 };
 
 /* Tensor ids for srx_read_tensor(), in graph order
@@ -127,8 +141,9 @@ srx_status srx_upscale_frames(srx_ctx* ctx, uint32_t first, uint32_t count, void
 srx_status srx_sync(srx_ctx* ctx, void* stream);
 
 /* Debug tap: copy a kept tensor of one frame to host as planar CHW fp16
- * (the reference's effective layout, Content/SuperResolution.cpp:155-159).
- * Needs SRX_FLAG_KEEP_TENSORS.  `bytes` must be C*H*W*2.  Synchronous. */
+ * (the reference's effective layout, Content/SuperResolution.cpp:155-159);
+ * fp32 with SRX_FLAG_FP32.  Needs SRX_FLAG_KEEP_TENSORS or a generic-layer
+ * ctx.  `bytes` must be C*H*W*2 (*4 for fp32).  Synchronous. */
 srx_status srx_read_tensor(srx_ctx* ctx, uint32_t frame, int32_t tensor_id,
                            void* fp16_chw_out, size_t bytes);
 srx_status srx_tensor_shape(const srx_ctx* ctx, int32_t tensor_id,
@@ -188,6 +203,28 @@ srx_status srx_pipe_input(srx_pipe* pipe, uint32_t slot, uint8_t** host_rgba,
 srx_status srx_pipe_submit(srx_pipe* pipe, uint32_t slot);
 srx_status srx_pipe_wait(srx_pipe* pipe, uint32_t slot, const uint8_t** host_rgba_out,
                          size_t* pitch, size_t* frame_stride);
+
+/*
+ * Generic layers: the operators the reference's layer factories build
+ * (ML::Util::CreateConvolutionLayer / CreateUpsampleLayer / CreateAdditionLayer,
+ * XUSG/MachineLearning/XUSGMachineLearning.h:847-854), run directly on dense
+ * DEVICE tensors of sizes {N, C, H, W}.  dtype: 0 = fp16 storage, 1 = fp32
+ * (arithmetic is fp32 either way); layout: 0 = NCHW, 1 = NHWC.
+ *   conv2d     : cross-correlation, stride 1, zero padding ceil((k-1)/2) before and
+ *                floor((k-1)/2) after, filter {O, I, kh, kw} (O,kh,kw,I order for NHWC),
+ *                kh, kw <= 7; bias != NULL adds the bias and applies ReLU
+ *                (useBiasAndActivation)
+ *   upsample2d : integer scales; interpolation 0 = nearest neighbour (pixel
+ *                replication), 1 = linear (half-pixel centres, clamped at the edges)
+ *   add        : element-wise, `out` may alias `a` or `b`
+ * Asynchronous on `stream`.
+ */
+srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const uint32_t in_sizes[4],
+                            const void* filter, const uint32_t filter_sizes[4], const void* bias,
+                            void* out, void* stream);
+srx_status srx_layer_upsample2d(int32_t dtype, int32_t layout, const void* in, const uint32_t in_sizes[4],
+                                uint32_t scale_x, uint32_t scale_y, int32_t interpolation, void* out, void* stream);
+srx_status srx_layer_add(int32_t dtype, const void* a, const void* b, void* out, size_t count, void* stream);
 
 /* Message of the last failure on this thread (never NULL). */
 const char* srx_last_error(void);

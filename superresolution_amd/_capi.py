@@ -9,6 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ASSETS_DIR = os.path.join(HERE, "Assets")
 FLAG_KEEP_TENSORS = 1
 FLAG_VERBOSE_WEIGHTS = 2
+FLAG_GENERIC_LAYERS = 4
+FLAG_FP32 = 8
+FLAG_NHWC = 16
 TENSOR_NAMES = ["input", "conv1", "conv2", "conv3", "conv_up1", "conv4", "conv5", "conv6", "output"]
 
 # every symbol include/srx.h declares
@@ -18,7 +21,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait"]
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add"]
 
 
 class SrxError(RuntimeError):
@@ -89,6 +92,10 @@ def lib():
     L.srx_pipe_input.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.srx_pipe_submit.argtypes = [vp, u32]
     L.srx_pipe_wait.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    u32x4 = C.POINTER(u32 * 4)
+    L.srx_layer_conv2d.argtypes = [i32, i32, vp, u32x4, vp, u32x4, vp, vp, vp]
+    L.srx_layer_upsample2d.argtypes = [i32, i32, vp, u32x4, u32, u32, i32, vp, vp]
+    L.srx_layer_add.argtypes = [i32, vp, vp, vp, sz, vp]
     for name in SYMBOLS:
         if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch", "srx_pipe_slots"):
             getattr(L, name).restype = i32
@@ -182,7 +189,7 @@ class SuperResolutionContext:
 
     def read_tensor(self, tid, frame=0):
         shape = self.tensor_shape(tid)
-        out = np.empty(shape, np.float16)
+        out = np.empty(shape, np.float32 if self.flags & FLAG_FP32 else np.float16)
         _check(self._L.srx_read_tensor(self._h, frame, tid, out.ctypes.data, out.nbytes))
         return out
 
@@ -243,6 +250,25 @@ class FramePipe:
         n = self.frames_per_slot * stride.value
         buf = (C.c_uint8 * n).from_address(ptr.value)
         return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, 4)
+
+
+def _sizes(v):
+    return (C.c_uint32 * 4)(*[int(x) for x in v])
+
+
+def layer_conv2d(dtype, layout, in_ptr, in_sizes, filter_ptr, filter_sizes, bias_ptr, out_ptr, stream=None):
+    """ML::Util::CreateConvolutionLayer + dispatch on device pointers (dtype 0 fp16 / 1 fp32, layout 0 NCHW / 1 NHWC)."""
+    _check(lib().srx_layer_conv2d(dtype, layout, in_ptr, C.byref(_sizes(in_sizes)), filter_ptr,
+                                  C.byref(_sizes(filter_sizes)), bias_ptr, out_ptr, stream))
+
+
+def layer_upsample2d(dtype, layout, in_ptr, in_sizes, scale_x, scale_y, interpolation, out_ptr, stream=None):
+    _check(lib().srx_layer_upsample2d(dtype, layout, in_ptr, C.byref(_sizes(in_sizes)), scale_x, scale_y,
+                                      interpolation, out_ptr, stream))
+
+
+def layer_add(dtype, a_ptr, b_ptr, out_ptr, count, stream=None):
+    _check(lib().srx_layer_add(dtype, a_ptr, b_ptr, out_ptr, count, stream))
 
 
 def fold_weights(layer, weights_path=None):

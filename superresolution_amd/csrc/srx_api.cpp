@@ -48,10 +48,10 @@ const TensorInfo kTensorInfo[SRX_T_COUNT] = {
 };
 
 // One kernel launch of the upscale sequence.
-enum StageKind { ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6, ST_HR_FUSED, ST_LR_FUSED };
+enum StageKind { ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6, ST_HR_FUSED, ST_LR_FUSED, ST_GENERIC };
 const char* const kStageNames[] = {"image_to_tensor", "conv1", "conv2", "conv3", "conv_up1",
                                    "conv4", "conv5", "conv6_add_unorm", "conv4_conv5_conv6_add_unorm",
-                                   "pack_conv1_conv2_conv3_conv_up1"};
+                                   "pack_conv1_conv2_conv3_conv_up1", "generic_layer_graph"};
 
 }  // namespace
 
@@ -79,7 +79,21 @@ struct srx_ctx
     std::vector<void*> allocs;
     std::vector<uint8_t> hostStage;
 
+    // the graph made of generic layers (SRX_FLAG_GENERIC_LAYERS / FP32 / NHWC)
+    struct Generic
+    {
+        srx::ML::TensorDataType dtype = srx::ML::TensorDataType::FLOAT16;
+        srx::ML::TensorLayout layout = srx::ML::TensorLayout::DEFAULT;
+        srx::ML::Operator up0, up1, conv[srx::kNumConvLayers], add;
+        void* filter[srx::kNumConvLayers] = {};
+        void* bias[srx::kNumConvLayers] = {};
+        void* t[SRX_T_COUNT] = {};            // {batch, C, H, W} each
+        void* up1Out = nullptr;               // conv3 upsampled, {batch, 64, 2H, 2W}
+        size_t elem() const { return dtype == srx::ML::TensorDataType::FLOAT16 ? 2 : 4; }
+    } gen;
+
     bool keep() const { return (flags & SRX_FLAG_KEEP_TENSORS) != 0; }
+    bool generic() const { return (flags & (SRX_FLAG_GENERIC_LAYERS | SRX_FLAG_FP32 | SRX_FLAG_NHWC)) != 0; }
 };
 
 namespace {
@@ -214,6 +228,81 @@ srx_status allocTensors(srx_ctx* c)
     return SRX_OK;
 }
 
+// The reference's createResources (Content/SuperResolution.cpp:172-275) and createWeightTensors
+// (:308-340) with the generic layer factories: same order of layers, same size bookkeeping.
+srx_status buildGenericGraph(srx_ctx* c, const srx::ML::WeightMapType& weights)
+{
+    using namespace srx;
+    srx_ctx::Generic& g = c->gen;
+    g.dtype = (c->flags & SRX_FLAG_FP32) ? ML::TensorDataType::FLOAT32 : ML::TensorDataType::FLOAT16;
+    g.layout = (c->flags & SRX_FLAG_NHWC) ? ML::TensorLayout::NHWC : ML::TensorLayout::DEFAULT;
+    const ML::Util util(g.dtype, g.layout);
+    uint64_t inBytes = 0, outBytes = 0;
+    const uint32_t inputSizes[4] = {c->batch, 3, c->height, c->width};
+    uint32_t sizes[SRX_T_COUNT][4] = {};
+    std::memcpy(sizes[SRX_T_INPUT], inputSizes, sizeof(inputSizes));
+    bool ok = util.CreateUpsampleLayer(inputSizes, inBytes, outBytes, sizes[SRX_T_OUTPUT], g.up0);
+    uint32_t cur[4];
+    std::memcpy(cur, inputSizes, sizeof(cur));
+    uint32_t up1Sizes[4] = {};
+    for (int l = 0; ok && l < kNumConvLayers; ++l)
+    {
+        if (l == 3)
+        {
+            ok = util.CreateUpsampleLayer(cur, inBytes, outBytes, up1Sizes, g.up1);
+            std::memcpy(cur, up1Sizes, sizeof(cur));
+        }
+        const ConvLayerDesc& d = kConvLayers[l];
+        ok = ok && util.CreateConvolutionLayer(cur, d.sizes, d.scale != nullptr, inBytes, outBytes, sizes[SRX_T_CONV1 + l], g.conv[l]);
+        std::memcpy(cur, sizes[SRX_T_CONV1 + l], sizeof(cur));
+    }
+    ok = ok && util.CreateAdditionLayer(sizes[SRX_T_OUTPUT], g.add);
+    if (!ok) return fail(SRX_ERR_INVALID, "generic graph: a layer factory rejected its sizes");
+
+    const auto count = [](const uint32_t s[4]) { return size_t(s[0]) * s[1] * s[2] * s[3]; };
+    for (int id = 0; id < SRX_T_COUNT; ++id)
+        if (const srx_status s = allocZero(c, &g.t[id], count(sizes[id]) * g.elem())) return s;
+    if (const srx_status s = allocZero(c, &g.up1Out, count(up1Sizes) * g.elem())) return s;
+    for (int l = 0; l < kNumConvLayers; ++l)
+    {
+        const ConvLayerDesc& d = kConvLayers[l];
+        std::vector<uint8_t> f, b;
+        if (!util.CreateWeightTensors(weights, d.conv, d.scale, d.shift, d.sizes, f, b))
+            return fail(SRX_ERR_WEIGHTS, "loadWeights: a layer's filter, scale or shift tensor is missing or has the wrong size");
+        if (const srx_status s = allocZero(c, &g.filter[l], f.size())) return s;
+        SRX_HIP(hipMemcpy(g.filter[l], f.data(), f.size(), hipMemcpyHostToDevice));
+        if (!b.empty())
+        {
+            if (const srx_status s = allocZero(c, &g.bias[l], b.size())) return s;
+            SRX_HIP(hipMemcpy(g.bias[l], b.data(), b.size(), hipMemcpyHostToDevice));
+        }
+    }
+    return SRX_OK;
+}
+
+// Dispatch order of SuperResolution::Process (Content/SuperResolution.cpp:73-103), then Render's pass.
+srx_status runGenericGraph(srx_ctx* c, hipStream_t s)
+{
+    using namespace srx;
+    srx_ctx::Generic& g = c->gen;
+    SRX_HIP(DispatchOperator(g.up0, g.t[SRX_T_INPUT], nullptr, nullptr, g.t[SRX_T_OUTPUT], s));
+    const void* cur = g.t[SRX_T_INPUT];
+    for (int l = 0; l < kNumConvLayers; ++l)
+    {
+        if (l == 3)
+        {
+            SRX_HIP(DispatchOperator(g.up1, cur, nullptr, nullptr, g.up1Out, s));
+            cur = g.up1Out;
+        }
+        SRX_HIP(DispatchOperator(g.conv[l], cur, g.filter[l], g.bias[l], g.t[SRX_T_CONV1 + l], s));
+        cur = g.t[SRX_T_CONV1 + l];
+    }
+    SRX_HIP(DispatchOperator(g.add, g.t[SRX_T_CONV6], g.t[SRX_T_OUTPUT], nullptr, g.t[SRX_T_OUTPUT], s));
+    SRX_HIP(LaunchTensorToImage(g.t[SRX_T_OUTPUT], c->output, g.dtype, g.layout, int(c->width) * 2, int(c->height) * 2,
+                                int(c->batch), s));
+    return SRX_OK;
+}
+
 srx::Tensor frameOffset(const srx::Tensor& t, uint32_t frame)
 {
     srx::Tensor r = t;
@@ -233,6 +322,7 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
 {
     using namespace srx;
     const int W = int(c->width), H = int(c->height);
+    if (stage == ST_GENERIC) return runGenericGraph(c, s);
     if (stage == ST_PACK)
     {
         SRX_HIP(LaunchPack(frameOffset(c->input, first), frameOffset(c->tensor[SRX_T_INPUT], first), W, H, int(count), s));
@@ -356,12 +446,21 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (const srx_status s = allocZero(c, &d, size_t(c->output.frame) * batch)) return bail(s);
     c->output.base = static_cast<uint8_t*>(d);
 
-    if (c->keep())
-        c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6};
+    if (c->generic())
+    {
+        c->stages = {ST_GENERIC};
+        c->chunk = batch;
+        if (const srx_status s = buildGenericGraph(c, weights)) return bail(s);
+    }
     else
-        c->stages = {ST_LR_FUSED, ST_HR_FUSED};
-    if (const srx_status s = uploadWeights(c)) return bail(s);
-    if (const srx_status s = allocTensors(c)) return bail(s);
+    {
+        if (c->keep())
+            c->stages = {ST_PACK, ST_CONV1, ST_CONV2, ST_CONV3, ST_CONV_UP1, ST_CONV4, ST_CONV5, ST_CONV6};
+        else
+            c->stages = {ST_LR_FUSED, ST_HR_FUSED};
+        if (const srx_status s = uploadWeights(c)) return bail(s);
+        if (const srx_status s = allocTensors(c)) return bail(s);
+    }
     {
         const hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)));
@@ -453,6 +552,12 @@ srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
+    if (c->generic())
+    {
+        SRX_HIP(srx::LaunchImageToTensor(c->input, c->gen.t[SRX_T_INPUT], c->gen.dtype, c->gen.layout, int(c->width),
+                                         int(c->height), int(c->batch), static_cast<hipStream_t>(stream)));
+        return SRX_OK;
+    }
     // the fused path converts the image inside its first kernel: nothing to launch here
     if (c->stages[0] != ST_PACK) return SRX_OK;
     return launchStage(c, ST_PACK, 0, c->batch, static_cast<hipStream_t>(stream));
@@ -481,7 +586,8 @@ srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* 
 {
     if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
         return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
-    if (c->keep()) return fail(SRX_ERR_STATE, "srx_upscale_frames: not available with SRX_FLAG_KEEP_TENSORS (kept tensors are indexed by frame of the whole batch)");
+    if (c->keep() || c->generic())
+        return fail(SRX_ERR_STATE, "srx_upscale_frames: not available with SRX_FLAG_KEEP_TENSORS or the generic-layer graph (their tensors are indexed by frame of the whole batch)");
     SRX_HIP(hipSetDevice(c->device));
     for (uint32_t f = first; f < first + count; f += c->chunk)
     {
@@ -498,7 +604,7 @@ srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t
     if (host && pitch < size_t(c->width) * 8) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: pitch too small");
     SRX_HIP(hipSetDevice(c->device));
     const hipStream_t st = static_cast<hipStream_t>(stream);
-    if (c->keep())
+    if (c->keep() && !c->generic())
         SRX_HIP(srx::LaunchUnpack(frameOffset(c->tensor[SRX_T_OUTPUT], frame), frameOffset(c->output, frame),
                                   int(c->width) * 2, int(c->height) * 2, 1, st));
     if (host)
@@ -529,9 +635,28 @@ srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, si
 {
     if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT || frame >= c->batch || !out)
         return fail(SRX_ERR_INVALID, "srx_read_tensor: bad argument");
-    if (!c->keep()) return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create");
+    if (!c->keep() && !c->generic()) return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create");
     const TensorInfo& ti = kTensorInfo[id];
     const size_t H = size_t(c->height) * ti.scale, W = size_t(c->width) * ti.scale;
+    if (c->generic())
+    {
+        const size_t es = c->gen.elem(), C = size_t(ti.channels), n = C * H * W;
+        if (bytes != n * es) return fail(SRX_ERR_INVALID, "srx_read_tensor: bytes != C*H*W*sizeof(element)");
+        SRX_HIP(hipSetDevice(c->device));
+        SRX_HIP(hipDeviceSynchronize());
+        const uint8_t* src = static_cast<const uint8_t*>(c->gen.t[id]) + size_t(frame) * n * es;
+        if (c->gen.layout != srx::ML::TensorLayout::NHWC)
+        {
+            SRX_HIP(hipMemcpy(out, src, n * es, hipMemcpyDeviceToHost));
+            return SRX_OK;
+        }
+        std::vector<uint8_t> raw(n * es);
+        SRX_HIP(hipMemcpy(raw.data(), src, n * es, hipMemcpyDeviceToHost));
+        uint8_t* dst = static_cast<uint8_t*>(out);
+        for (size_t ch = 0; ch < C; ++ch)
+            for (size_t i = 0; i < H * W; ++i) std::memcpy(dst + (ch * H * W + i) * es, raw.data() + (i * C + ch) * es, es);
+        return SRX_OK;
+    }
     if (bytes != size_t(ti.channels) * H * W * 2) return fail(SRX_ERR_INVALID, "srx_read_tensor: bytes != C*H*W*2");
     SRX_HIP(hipSetDevice(c->device));
     SRX_HIP(hipDeviceSynchronize());
@@ -608,6 +733,63 @@ srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
 }
 
 // ---------------------------------------------------------------------------
+// Generic layers on caller tensors.
+// ---------------------------------------------------------------------------
+namespace {
+bool utilFor(int32_t dtype, int32_t layout, srx::ML::Util& out)
+{
+    if ((dtype != 0 && dtype != 1) || (layout != 0 && layout != 1)) return false;
+    out = srx::ML::Util(dtype == 0 ? srx::ML::TensorDataType::FLOAT16 : srx::ML::TensorDataType::FLOAT32,
+                        layout == 0 ? srx::ML::TensorLayout::DEFAULT : srx::ML::TensorLayout::NHWC);
+    return true;
+}
+}  // namespace
+
+srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const uint32_t inSizes[4], const void* filter,
+                            const uint32_t filterSizes[4], const void* bias, void* out, void* stream)
+{
+    srx::ML::Util util;
+    srx::ML::Operator op;
+    uint64_t ib = 0, ob = 0;
+    uint32_t outSizes[4];
+    if (!in || !inSizes || !filter || !filterSizes || !out || !utilFor(dtype, layout, util) ||
+        filterSizes[2] > 7 || filterSizes[3] > 7 ||
+        !util.CreateConvolutionLayer(inSizes, filterSizes, bias != nullptr, ib, ob, outSizes, op))
+        return fail(SRX_ERR_INVALID, "srx_layer_conv2d: bad pointer, data type, layout or sizes (filter depth must equal the input channels, sides <= 7)");
+    SRX_HIP(srx::DispatchOperator(op, in, filter, bias, out, static_cast<hipStream_t>(stream)));
+    return SRX_OK;
+}
+
+srx_status srx_layer_upsample2d(int32_t dtype, int32_t layout, const void* in, const uint32_t inSizes[4], uint32_t scaleX,
+                                uint32_t scaleY, int32_t interpolation, void* out, void* stream)
+{
+    srx::ML::Util util;
+    srx::ML::Operator op;
+    uint64_t ib = 0, ob = 0;
+    uint32_t outSizes[4];
+    if (!in || !inSizes || !out || !utilFor(dtype, layout, util) || (interpolation != 0 && interpolation != 1) ||
+        !util.CreateUpsampleLayer(inSizes, ib, ob, outSizes, op, scaleX, scaleY,
+                                  interpolation ? srx::ML::InterpolationType::LINEAR : srx::ML::InterpolationType::NEAREST_NEIGHBOR))
+        return fail(SRX_ERR_INVALID, "srx_layer_upsample2d: bad pointer, data type, layout, sizes, scale or interpolation");
+    SRX_HIP(srx::DispatchOperator(op, in, nullptr, nullptr, out, static_cast<hipStream_t>(stream)));
+    return SRX_OK;
+}
+
+srx_status srx_layer_add(int32_t dtype, const void* a, const void* b, void* out, size_t count, void* stream)
+{
+    srx::ML::Util util;
+    srx::ML::Operator op;
+    const uint32_t sizes[4] = {1, 1, uint32_t(count >> 20) + 1, 1u << 20};   // only the element count matters
+    if (!a || !b || !out || count == 0 || !utilFor(dtype, 0, util) || !util.CreateAdditionLayer(sizes, op))
+        return fail(SRX_ERR_INVALID, "srx_layer_add: bad pointer, data type or count");
+    op.inputSizes[0] = op.inputSizes[1] = op.inputSizes[2] = 1;
+    if (count >= (size_t(1) << 32)) return fail(SRX_ERR_INVALID, "srx_layer_add: count must be below 2^32");
+    op.inputSizes[3] = uint32_t(count);
+    SRX_HIP(srx::DispatchOperator(op, a, b, nullptr, out, static_cast<hipStream_t>(stream)));
+    return SRX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Frame pipe: pinned staging buffers and three streams around srx_upscale_frames.
 // ---------------------------------------------------------------------------
 struct srx_pipe
@@ -643,7 +825,7 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out)
     *out = nullptr;
     if (!validCtx(c) || framesPerSlot == 0 || c->batch / framesPerSlot < 2)
         return fail(SRX_ERR_INVALID, "srx_pipe_create: the ctx's batch must hold at least two slots of frames_per_slot frames");
-    if (c->keep()) return fail(SRX_ERR_STATE, "srx_pipe_create: not available with SRX_FLAG_KEEP_TENSORS");
+    if (c->keep() || c->generic()) return fail(SRX_ERR_STATE, "srx_pipe_create: not available with SRX_FLAG_KEEP_TENSORS or the generic-layer graph");
     SRX_HIP(hipSetDevice(c->device));
     srx_pipe* p = new srx_pipe;
     p->ctx = c;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "srx_weights.h"
+
 namespace srx {
 
 // An activation tensor in HBM: NHWC fp16 with a zero border of `border` pixels
@@ -94,6 +96,17 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s);
+
+// Generic layers (srx_layers.hip): run an operator made by ML::Util::Create*Layer on dense device
+// tensors.  CONVOLUTION: (input, filter, bias or nullptr, output); UPSAMPLE_2D: (input, -, -, output);
+// ELEMENT_WISE_ADD: (a, b, -, output), output may alias a or b.
+hipError_t DispatchOperator(const ML::Operator& op, const void* input, const void* filterOrB, const void* bias,
+                            void* output, hipStream_t s);
+// CSImageToTensor / PSTensorToImage for a {batch, 3, height, width} tensor of any data type and layout.
+hipError_t LaunchImageToTensor(const Image& src, void* tensor, ML::TensorDataType t, ML::TensorLayout layout,
+                               int width, int height, int batch, hipStream_t s);
+hipError_t LaunchTensorToImage(const void* tensor, const Image& dst, ML::TensorDataType t, ML::TensorLayout layout,
+                               int width, int height, int batch, hipStream_t s);
 
 constexpr int kTileW = 32;   // output pixels per MFMA column tile
 constexpr int kTileH = 8;    // output rows per workgroup tile

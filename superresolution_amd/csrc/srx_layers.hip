@@ -1,0 +1,294 @@
+// gfx950 kernels of the generic layers: the operators the reference's layer factories create
+// (ML::Util::CreateUpsampleLayer / CreateConvolutionLayer / CreateAdditionLayer,
+// XUSG/MachineLearning/XUSGMachineLearning.h:847-854), for any tensor size, filter size, data type
+// (fp16 or fp32 storage, fp32 arithmetic) and layout (NCHW or NHWC), plus the two shader passes
+// (CSImageToTensor.hlsl, PSTensorToImage.hlsl) for those data types and layouts.
+//
+// These are direct, LDS-tiled VALU kernels: they serve the fp32 tensor mode, the NHWC switch and
+// other small networks.  The fp16 fast path of the sample network does not use them (it runs on the
+// fused MFMA kernels).
+#include "srx_device.h"
+#include "srx_weights.h"
+
+namespace srx {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kTW = 32, kTH = 8;      // output pixels per workgroup tile
+constexpr int kOT = 16;               // output channels per workgroup
+constexpr int kCC = 8;                // input channels staged per pass
+constexpr int kKMax = 7;              // largest filter side
+
+__device__ __forceinline__ float loadF(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float loadF(const f16* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ void storeF(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void storeF(f16* p, size_t i, float v) { p[i] = (f16)v; }   // round to nearest even
+
+// Element (n, c, y, x) of a dense {N, C, H, W} tensor (ML::Util::GetStrides, XUSGMachineLearning.h:860).
+template <bool NHWC>
+__device__ __forceinline__ size_t at(int n, int c, int y, int x, int C, int H, int W)
+{
+    return NHWC ? ((size_t(n) * H + y) * W + x) * C + c : ((size_t(n) * C + c) * H + y) * W + x;
+}
+
+struct ConvArgs
+{
+    const void *in, *filter, *bias;
+    void* out;
+    int N, C, H, W, O, kh, kw, padTop, padLeft, relu;
+    int tilesX, tilesY;
+};
+
+// out[n,o,y,x] = act(bias[o] + sum_{c,i,j} in[n,c,y+i-padTop,x+j-padLeft] * w[o,c,i,j]), zero padding.
+// The filter is OIHW for NCHW tensors and O,kh,kw,I for NHWC tensors (as CreateWeightTensors lays it out).
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void ConvDirectKernel(const ConvArgs a)
+{
+    __shared__ float sIn[kCC][kTH + kKMax - 1][kTW + kKMax];
+    __shared__ float sW[kCC][kKMax * kKMax][kOT];
+    const T* in = static_cast<const T*>(a.in);
+    const T* filter = static_cast<const T*>(a.filter);
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int tile = blockIdx.x, n = blockIdx.z, o0 = blockIdx.y * kOT;
+    const int x0 = (tile % a.tilesX) * kTW, y0 = (tile / a.tilesX) * kTH;
+    const int inH = kTH + a.kh - 1, inW = kTW + a.kw - 1, taps = a.kh * a.kw;
+
+    float acc[kOT];
+#pragma unroll
+    for (int o = 0; o < kOT; ++o) acc[o] = 0.0f;
+
+    for (int c0 = 0; c0 < a.C; c0 += kCC)
+    {
+        const int cn = min(kCC, a.C - c0);
+        __syncthreads();
+        for (int i = tid; i < cn * inH * inW; i += 256)
+        {
+            const int c = i / (inH * inW), r = i - c * inH * inW, yy = r / inW, xx = r - yy * inW;
+            const int y = y0 + yy - a.padTop, x = x0 + xx - a.padLeft;
+            sIn[c][yy][xx] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? loadF(in, at<NHWC>(n, c0 + c, y, x, a.C, a.H, a.W)) : 0.0f;
+        }
+        for (int i = tid; i < cn * taps * kOT; i += 256)
+        {
+            const int o = i % kOT, r = i / kOT, t = r % taps, c = r / taps;
+            float v = 0.0f;
+            if (o0 + o < a.O)
+            {
+                const int ki = t / a.kw, kj = t - ki * a.kw;
+                // the filter seen as a tensor {O, I, kh, kw} in the operator's layout
+                v = loadF(filter, at<NHWC>(o0 + o, c0 + c, ki, kj, a.C, a.kh, a.kw));
+            }
+            sW[c][t][o] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < cn; ++c)
+            for (int ki = 0; ki < a.kh; ++ki)
+                for (int kj = 0; kj < a.kw; ++kj)
+                {
+                    const float v = sIn[c][ty + ki][tx + kj];
+                    const float4* w4 = reinterpret_cast<const float4*>(&sW[c][ki * a.kw + kj][0]);
+#pragma unroll
+                    for (int g = 0; g < kOT / 4; ++g)
+                    {
+                        const float4 w = w4[g];
+                        acc[4 * g + 0] = fmaf(v, w.x, acc[4 * g + 0]);
+                        acc[4 * g + 1] = fmaf(v, w.y, acc[4 * g + 1]);
+                        acc[4 * g + 2] = fmaf(v, w.z, acc[4 * g + 2]);
+                        acc[4 * g + 3] = fmaf(v, w.w, acc[4 * g + 3]);
+                    }
+                }
+    }
+
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= a.W || y >= a.H) return;
+    T* out = static_cast<T*>(a.out);
+#pragma unroll
+    for (int o = 0; o < kOT; ++o)
+    {
+        if (o0 + o >= a.O) break;
+        float v = acc[o];
+        if (a.bias) v += loadF(static_cast<const T*>(a.bias), size_t(o0 + o));
+        if (a.relu) v = fmaxf(v, 0.0f);
+        storeF(out, at<NHWC>(n, o0 + o, y, x, a.O, a.H, a.W), v);
+    }
+}
+
+struct UpsampleArgs
+{
+    const void* in;
+    void* out;
+    int N, C, H, W, sx, sy, linear;
+    size_t total;
+};
+
+// DML UPSAMPLE_2D.  NEAREST_NEIGHBOR with an integer scale replicates pixels: out[y][x] = in[y / sy][x / sx].
+// LINEAR samples with pixel centres at half-integers and clamps at the edges.
+template <typename T, bool NHWC>
+__global__ void UpsampleKernel(const UpsampleArgs a)
+{
+    const int OH = a.H * a.sy, OW = a.W * a.sx;
+    const T* in = static_cast<const T*>(a.in);
+    T* out = static_cast<T*>(a.out);
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.total; i += size_t(gridDim.x) * blockDim.x)
+    {
+        int n, c, y, x;
+        size_t r = i;
+        if (NHWC) { c = int(r % a.C); r /= a.C; x = int(r % OW); r /= OW; y = int(r % OH); n = int(r / OH); }
+        else { x = int(r % OW); r /= OW; y = int(r % OH); r /= OH; c = int(r % a.C); n = int(r / a.C); }
+        float v;
+        if (!a.linear) v = loadF(in, at<NHWC>(n, c, y / a.sy, x / a.sx, a.C, a.H, a.W));
+        else
+        {
+            const float fy = fminf(fmaxf((y + 0.5f) / a.sy - 0.5f, 0.0f), float(a.H - 1));
+            const float fx = fminf(fmaxf((x + 0.5f) / a.sx - 0.5f, 0.0f), float(a.W - 1));
+            const int y0 = int(fy), x0 = int(fx), y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+            const float wy = fy - y0, wx = fx - x0;
+            const float v00 = loadF(in, at<NHWC>(n, c, y0, x0, a.C, a.H, a.W)), v01 = loadF(in, at<NHWC>(n, c, y0, x1, a.C, a.H, a.W));
+            const float v10 = loadF(in, at<NHWC>(n, c, y1, x0, a.C, a.H, a.W)), v11 = loadF(in, at<NHWC>(n, c, y1, x1, a.C, a.H, a.W));
+            v = (v00 * (1.0f - wx) + v01 * wx) * (1.0f - wy) + (v10 * (1.0f - wx) + v11 * wx) * wy;
+        }
+        storeF(out, i, v);
+    }
+}
+
+// DML ELEMENT_WISE_ADD; out may alias a or b (the reference binds it in place, Content/SuperResolution.cpp:700-702).
+template <typename T>
+__global__ void AddKernel(const T* a, const T* b, T* out, size_t total)
+{
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x)
+        storeF(out, i, loadF(a, i) + loadF(b, i));
+}
+
+// CSImageToTensor.hlsl:15-45: texel.rgb as UNORM floats into a {N, 3, H, W} tensor (plane = H * W).
+template <typename T, bool NHWC>
+__global__ void ImageToTensorKernel(const uint8_t* img, long pitch, long frame, T* out, int N, int H, int W)
+{
+    const size_t total = size_t(N) * H * W;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x)
+    {
+        const int x = int(i % W), y = int((i / W) % H), n = int(i / (size_t(W) * H));
+        const unsigned v = *reinterpret_cast<const unsigned*>(img + n * frame + y * pitch + x * 4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) storeF(out, at<NHWC>(n, c, y, x, 3, H, W), float((v >> (8 * c)) & 0xff) / 255.0f);
+    }
+}
+
+// PSTensorToImage.hlsl:14-35 + the R8G8B8A8_UNORM render target.
+template <typename T, bool NHWC>
+__global__ void TensorToImageKernel(const T* in, uint8_t* img, long pitch, long frame, int N, int H, int W)
+{
+    const size_t total = size_t(N) * H * W;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x)
+    {
+        const int x = int(i % W), y = int((i / W) % H), n = int(i / (size_t(W) * H));
+        unsigned rgba = 0xff000000u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgba |= unorm8(loadF(in, at<NHWC>(n, c, y, x, 3, H, W))) << (8 * c);
+        *reinterpret_cast<unsigned*>(img + n * frame + y * pitch + x * 4) = rgba;
+    }
+}
+
+int gridForElements(size_t total)
+{
+    const size_t blocks = (total + 255) / 256;
+    return int(blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks));
+}
+
+template <typename F16, typename F32>
+hipError_t byType(ML::TensorDataType t, F16&& f16, F32&& f32)
+{
+    if (t == ML::TensorDataType::FLOAT16) f16();
+    else if (t == ML::TensorDataType::FLOAT32) f32();
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t DispatchOperator(const ML::Operator& op, const void* input, const void* filterOrB, const void* bias,
+                            void* output, hipStream_t s)
+{
+    using K = ML::Operator::Kind;
+    const bool nhwc = op.layout == ML::TensorLayout::NHWC;
+    if (!input || !output) return hipErrorInvalidValue;
+    if (op.kind == K::CONVOLUTION)
+    {
+        if (!filterOrB || op.filterSizes[2] > kKMax || op.filterSizes[3] > kKMax) return hipErrorInvalidValue;
+        ConvArgs a{};
+        a.in = input;
+        a.filter = filterOrB;
+        a.bias = op.useBiasAndActivation ? bias : nullptr;
+        if (op.useBiasAndActivation && !bias) return hipErrorInvalidValue;
+        a.out = output;
+        a.N = int(op.inputSizes[0]); a.C = int(op.inputSizes[1]); a.H = int(op.inputSizes[2]); a.W = int(op.inputSizes[3]);
+        a.O = int(op.filterSizes[0]); a.kh = int(op.filterSizes[2]); a.kw = int(op.filterSizes[3]);
+        a.padTop = int(op.padTop); a.padLeft = int(op.padLeft);
+        a.relu = op.useBiasAndActivation ? 1 : 0;
+        a.tilesX = (a.W + kTW - 1) / kTW;
+        a.tilesY = (a.H + kTH - 1) / kTH;
+        if (a.N > 65535 || (a.O + kOT - 1) / kOT > 65535) return hipErrorInvalidValue;
+        const dim3 grid(a.tilesX * a.tilesY, (a.O + kOT - 1) / kOT, a.N), block(256);
+        return byType(op.dataType,
+                      [&] { if (nhwc) hipLaunchKernelGGL((ConvDirectKernel<f16, true>), grid, block, 0, s, a);
+                            else hipLaunchKernelGGL((ConvDirectKernel<f16, false>), grid, block, 0, s, a); },
+                      [&] { if (nhwc) hipLaunchKernelGGL((ConvDirectKernel<float, true>), grid, block, 0, s, a);
+                            else hipLaunchKernelGGL((ConvDirectKernel<float, false>), grid, block, 0, s, a); });
+    }
+    if (op.kind == K::UPSAMPLE_2D)
+    {
+        UpsampleArgs a{};
+        a.in = input;
+        a.out = output;
+        a.N = int(op.inputSizes[0]); a.C = int(op.inputSizes[1]); a.H = int(op.inputSizes[2]); a.W = int(op.inputSizes[3]);
+        a.sx = int(op.scaleX); a.sy = int(op.scaleY);
+        a.linear = op.interpolation == ML::InterpolationType::LINEAR;
+        a.total = size_t(a.N) * a.C * a.H * a.sy * a.W * a.sx;
+        const dim3 grid(gridForElements(a.total)), block(256);
+        return byType(op.dataType,
+                      [&] { if (nhwc) hipLaunchKernelGGL((UpsampleKernel<f16, true>), grid, block, 0, s, a);
+                            else hipLaunchKernelGGL((UpsampleKernel<f16, false>), grid, block, 0, s, a); },
+                      [&] { if (nhwc) hipLaunchKernelGGL((UpsampleKernel<float, true>), grid, block, 0, s, a);
+                            else hipLaunchKernelGGL((UpsampleKernel<float, false>), grid, block, 0, s, a); });
+    }
+    if (op.kind == K::ELEMENT_WISE_ADD)
+    {
+        if (!filterOrB) return hipErrorInvalidValue;
+        const size_t total = size_t(op.inputSizes[0]) * op.inputSizes[1] * op.inputSizes[2] * op.inputSizes[3];
+        const dim3 grid(gridForElements(total)), block(256);
+        return byType(op.dataType,
+                      [&] { hipLaunchKernelGGL(AddKernel<f16>, grid, block, 0, s, static_cast<const f16*>(input),
+                                               static_cast<const f16*>(filterOrB), static_cast<f16*>(output), total); },
+                      [&] { hipLaunchKernelGGL(AddKernel<float>, grid, block, 0, s, static_cast<const float*>(input),
+                                               static_cast<const float*>(filterOrB), static_cast<float*>(output), total); });
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t LaunchImageToTensor(const Image& src, void* tensor, ML::TensorDataType t, ML::TensorLayout layout,
+                               int width, int height, int batch, hipStream_t s)
+{
+    const bool nhwc = layout == ML::TensorLayout::NHWC;
+    const dim3 grid(gridForElements(size_t(batch) * width * height)), block(256);
+    const long pitch = long(src.pitch), frame = long(src.frame);
+    return byType(t,
+                  [&] { if (nhwc) hipLaunchKernelGGL((ImageToTensorKernel<f16, true>), grid, block, 0, s, src.base, pitch, frame, static_cast<f16*>(tensor), batch, height, width);
+                        else hipLaunchKernelGGL((ImageToTensorKernel<f16, false>), grid, block, 0, s, src.base, pitch, frame, static_cast<f16*>(tensor), batch, height, width); },
+                  [&] { if (nhwc) hipLaunchKernelGGL((ImageToTensorKernel<float, true>), grid, block, 0, s, src.base, pitch, frame, static_cast<float*>(tensor), batch, height, width);
+                        else hipLaunchKernelGGL((ImageToTensorKernel<float, false>), grid, block, 0, s, src.base, pitch, frame, static_cast<float*>(tensor), batch, height, width); });
+}
+
+hipError_t LaunchTensorToImage(const void* tensor, const Image& dst, ML::TensorDataType t, ML::TensorLayout layout,
+                               int width, int height, int batch, hipStream_t s)
+{
+    const bool nhwc = layout == ML::TensorLayout::NHWC;
+    const dim3 grid(gridForElements(size_t(batch) * width * height)), block(256);
+    const long pitch = long(dst.pitch), frame = long(dst.frame);
+    return byType(t,
+                  [&] { if (nhwc) hipLaunchKernelGGL((TensorToImageKernel<f16, true>), grid, block, 0, s, static_cast<const f16*>(tensor), dst.base, pitch, frame, batch, height, width);
+                        else hipLaunchKernelGGL((TensorToImageKernel<f16, false>), grid, block, 0, s, static_cast<const f16*>(tensor), dst.base, pitch, frame, batch, height, width); },
+                  [&] { if (nhwc) hipLaunchKernelGGL((TensorToImageKernel<float, true>), grid, block, 0, s, static_cast<const float*>(tensor), dst.base, pitch, frame, batch, height, width);
+                        else hipLaunchKernelGGL((TensorToImageKernel<float, false>), grid, block, 0, s, static_cast<const float*>(tensor), dst.base, pitch, frame, batch, height, width); });
+}
+
+}  // namespace srx

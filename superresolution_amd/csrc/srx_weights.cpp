@@ -1,5 +1,7 @@
 #include "srx_weights.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -69,6 +71,89 @@ uint16_t Float32ToFloat16(float v)
     if (da < db) return lo;
     if (db < da) return hi;
     return (lo & 1u) ? hi : lo;
+}
+
+namespace {
+
+uint64_t tensorBytes(const uint32_t sizes[4], TensorDataType t)
+{
+    return uint64_t(sizes[0]) * sizes[1] * sizes[2] * sizes[3] * (t == TensorDataType::FLOAT16 ? 2 : 4);
+}
+
+bool validSizes(const uint32_t sizes[4])
+{
+    return sizes && sizes[0] && sizes[1] && sizes[2] && sizes[3] &&
+           uint64_t(sizes[0]) * sizes[1] * sizes[2] * sizes[3] < (uint64_t(1) << 40);
+}
+
+}  // namespace
+
+bool Util::CreateUpsampleLayer(const uint32_t inputSizes[4], uint64_t& inputBufferRequiredSize,
+                               uint64_t& outputBufferRequiredSize, uint32_t outputSizes[4], Operator& opOut,
+                               uint32_t scaleSizeX, uint32_t scaleSizeY, InterpolationType interpolationType) const
+{
+    if (!validSizes(inputSizes) || !outputSizes || scaleSizeX == 0 || scaleSizeY == 0) return false;
+    if (m_dataType == TensorDataType::UNKNOWN) return false;
+    opOut = Operator{};
+    opOut.kind = Operator::Kind::UPSAMPLE_2D;
+    opOut.dataType = m_dataType;
+    opOut.layout = m_layout;
+    opOut.scaleX = scaleSizeX;
+    opOut.scaleY = scaleSizeY;
+    opOut.interpolation = interpolationType;
+    outputSizes[0] = inputSizes[0];
+    outputSizes[1] = inputSizes[1];
+    outputSizes[2] = inputSizes[2] * scaleSizeY;
+    outputSizes[3] = inputSizes[3] * scaleSizeX;
+    if (!validSizes(outputSizes)) return false;
+    for (int i = 0; i < 4; ++i)
+    {
+        opOut.inputSizes[i] = inputSizes[i];
+        opOut.outputSizes[i] = outputSizes[i];
+    }
+    inputBufferRequiredSize = std::max(inputBufferRequiredSize, tensorBytes(inputSizes, m_dataType));
+    outputBufferRequiredSize = std::max(outputBufferRequiredSize, tensorBytes(outputSizes, m_dataType));
+    return true;
+}
+
+bool Util::CreateConvolutionLayer(const uint32_t inputSizes[4], const uint32_t* filterSizes, bool useBiasAndActivation,
+                                  uint64_t& inputBufferRequiredSize, uint64_t& outputBufferRequiredSize,
+                                  uint32_t outputSizes[4], Operator& opOut) const
+{
+    if (!validSizes(inputSizes) || !validSizes(filterSizes) || !outputSizes) return false;
+    if (m_dataType == TensorDataType::UNKNOWN) return false;
+    if (filterSizes[1] != inputSizes[1]) return false;                  // group count 1: filter depth = input channels
+    opOut = Operator{};
+    opOut.kind = Operator::Kind::CONVOLUTION;
+    opOut.dataType = m_dataType;
+    opOut.layout = m_layout;
+    opOut.useBiasAndActivation = useBiasAndActivation;
+    opOut.padTop = filterSizes[2] / 2;                                   // ceil((k - 1) / 2)
+    opOut.padLeft = filterSizes[3] / 2;
+    outputSizes[0] = inputSizes[0];
+    outputSizes[1] = filterSizes[0];
+    outputSizes[2] = inputSizes[2];
+    outputSizes[3] = inputSizes[3];
+    for (int i = 0; i < 4; ++i)
+    {
+        opOut.inputSizes[i] = inputSizes[i];
+        opOut.outputSizes[i] = outputSizes[i];
+        opOut.filterSizes[i] = filterSizes[i];
+    }
+    inputBufferRequiredSize = std::max(inputBufferRequiredSize, tensorBytes(inputSizes, m_dataType));
+    outputBufferRequiredSize = std::max(outputBufferRequiredSize, tensorBytes(outputSizes, m_dataType));
+    return true;
+}
+
+bool Util::CreateAdditionLayer(const uint32_t inputSizes[4], Operator& opOut) const
+{
+    if (!validSizes(inputSizes) || m_dataType == TensorDataType::UNKNOWN) return false;
+    opOut = Operator{};
+    opOut.kind = Operator::Kind::ELEMENT_WISE_ADD;
+    opOut.dataType = m_dataType;
+    opOut.layout = m_layout;
+    for (int i = 0; i < 4; ++i) opOut.inputSizes[i] = opOut.outputSizes[i] = inputSizes[i];
+    return true;
 }
 
 bool Util::CreateWeightTensors(const WeightMapType& weights, const char* convLayerName,

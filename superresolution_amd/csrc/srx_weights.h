@@ -31,6 +31,24 @@ float Float16ToFloat32(uint16_t h);
 // IEEE round-to-nearest-even, used only for the summed phase weights of conv_up1.
 uint16_t Float32ToFloat16(float v);
 
+enum class InterpolationType : uint32_t { NEAREST_NEIGHBOR, LINEAR };   // XUSGMachineLearning.h:177-181
+
+// What a layer factory returns: the counterpart of the reference's compiled DirectML operator
+// (XUSG::ML::Operator), reduced to the description a kernel launch needs.  Sizes are {N, C, H, W}.
+struct Operator
+{
+    enum class Kind : uint32_t { NONE, UPSAMPLE_2D, CONVOLUTION, ELEMENT_WISE_ADD };
+    Kind kind = Kind::NONE;
+    TensorDataType dataType = TensorDataType::FLOAT16;
+    TensorLayout layout = TensorLayout::DEFAULT;
+    uint32_t inputSizes[4] = {}, outputSizes[4] = {};
+    uint32_t filterSizes[4] = {};                  // {O, I, kh, kw}
+    uint32_t padTop = 0, padLeft = 0;              // ceil((k-1)/2); bottom / right get floor((k-1)/2)
+    bool useBiasAndActivation = false;             // bias + fused ReLU
+    uint32_t scaleX = 1, scaleY = 1;
+    InterpolationType interpolation = InterpolationType::NEAREST_NEIGHBOR;
+};
+
 class Util
 {
 public:
@@ -47,6 +65,24 @@ public:
                              std::vector<uint8_t>& biasWeightsOut) const;
 
     static void GetStrides(const uint32_t sizes[4], TensorLayout layout, uint32_t stridesOut[4]);
+
+    // Layer factories with the reference's signatures minus the D3D12 device
+    // (XUSGMachineLearning.h:847-854).  They validate the sizes, report the byte sizes of the
+    // input and output tensors (the reference tracks the running maximum: the arguments are
+    // raised, never lowered), fill outputSizes and describe the operator.
+    bool CreateUpsampleLayer(const uint32_t inputSizes[4], uint64_t& inputBufferRequiredSize,
+                             uint64_t& outputBufferRequiredSize, uint32_t outputSizes[4], Operator& opOut,
+                             uint32_t scaleSizeX = 2, uint32_t scaleSizeY = 2,
+                             InterpolationType interpolationType = InterpolationType::NEAREST_NEIGHBOR) const;
+    // Cross-correlation, stride 1, zero padding ceil((k-1)/2) before and floor((k-1)/2) after, so the
+    // output has the input's height and width; bias and ReLU iff useBiasAndActivation.
+    bool CreateConvolutionLayer(const uint32_t inputSizes[4], const uint32_t* filterSizes, bool useBiasAndActivation,
+                                uint64_t& inputBufferRequiredSize, uint64_t& outputBufferRequiredSize,
+                                uint32_t outputSizes[4], Operator& opOut) const;
+    bool CreateAdditionLayer(const uint32_t inputSizes[4], Operator& opOut) const;
+
+    TensorDataType GetDataType() const { return m_dataType; }
+    TensorLayout GetLayout() const { return m_layout; }
 
 private:
     TensorDataType m_dataType;
