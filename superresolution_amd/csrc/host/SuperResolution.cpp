@@ -24,13 +24,14 @@ SuperResolution::~SuperResolution()
     srx_destroy(m_ctx);
 }
 
-bool SuperResolution::Init(void* stream, int device, uint32_t /*vendorId*/, const char* fileName, bool isFP16Supported)
+bool SuperResolution::Init(void* stream, int device, uint32_t vendorId, const char* fileName, bool isFP16Supported)
 {
-    if (!isFP16Supported)
-    {
-        cerr << "SuperResolution: only the fp16 tensor path exists on this device" << endl;
-        return false;
-    }
+    // Content/SuperResolution.cpp:155-163: NHWC tensors for the vendor that prefers them, fp32 tensors
+    // without fp16 support.  Either choice runs the graph of generic layers; the default (fp16, any
+    // other vendor) runs the fused MFMA kernels, whose internal layout is their own.
+    uint32_t flags = SRX_FLAG_VERBOSE_WEIGHTS;
+    if (!isFP16Supported) flags |= SRX_FLAG_FP32;
+    if (vendorId == 0x10DE) flags |= SRX_FLAG_NHWC;
 
     // Load input image: 3-channel files become RGBA, 1-/2-channel files keep their channels and
     // the missing ones read as 0 (alpha 1) like a D3D R8 / R8G8 texture sampled as float3.
@@ -54,7 +55,7 @@ bool SuperResolution::Init(void* stream, int device, uint32_t /*vendorId*/, cons
     m_imageLayoutIn.Width = static_cast<uint32_t>(width);
     m_imageLayoutIn.Height = static_cast<uint32_t>(height);
 
-    if (!createResources(device)) return false;
+    if (!createResources(device, flags)) return false;
     if (srx_upload_rgba8(m_ctx, 0, m_inputImage.data(), size_t(width) * 4, stream) != SRX_OK ||
         srx_sync(m_ctx, stream) != SRX_OK)
     {
@@ -64,18 +65,17 @@ bool SuperResolution::Init(void* stream, int device, uint32_t /*vendorId*/, cons
 
     m_imageLayoutOut.Width = m_imageLayoutIn.Width << 1;
     m_imageLayoutOut.Height = m_imageLayoutIn.Height << 1;
-    m_imageLayoutOut.UseNhwc = m_imageLayoutIn.UseNhwc = true;   // internal layout of the HIP kernels
+    m_imageLayoutOut.UseNhwc = m_imageLayoutIn.UseNhwc = (flags & SRX_FLAG_NHWC) != 0;
     return true;
 }
 
-bool SuperResolution::createResources(int device)
+bool SuperResolution::createResources(int device, uint32_t flags)
 {
     // "Assets/weights.bin" relative to the working directory, as in the reference; SRX_ASSETS names
     // another directory.
     string path = "Assets/weights.bin";
     if (const char* dir = getenv("SRX_ASSETS")) path = string(dir) + "/weights.bin";
-    const srx_status s = srx_create(&m_ctx, device, path.c_str(), m_imageLayoutIn.Width, m_imageLayoutIn.Height, 1,
-                                    SRX_FLAG_VERBOSE_WEIGHTS);
+    const srx_status s = srx_create(&m_ctx, device, path.c_str(), m_imageLayoutIn.Width, m_imageLayoutIn.Height, 1, flags);
     if (s == SRX_ERR_WEIGHTS) throw std::runtime_error("loadWeights");
     if (s != SRX_OK)
     {

@@ -31,9 +31,9 @@ public:
     SuperResolution();
     virtual ~SuperResolution();
 
-    // vendorId only chose the tensor layout in the reference (Content/SuperResolution.cpp:155-159);
-    // the HIP kernels use one internal layout, so it is accepted and ignored.  isFP16Supported
-    // must be true: this library computes in fp16 storage / fp32 accumulate only.
+    // As in the reference (Content/SuperResolution.cpp:155-163) vendorId 0x10DE selects NHWC tensors
+    // and isFP16Supported == false fp32 tensors; both run the graph made of generic layers.  The
+    // default runs the fused fp16 MFMA kernels.
     bool Init(void* stream, int device, uint32_t vendorId, const char* fileName, bool isFP16Supported = true);
 
     void ImageToTensors(void* stream);
@@ -51,7 +51,7 @@ protected:
         bool UseNhwc;
     };
 
-    bool createResources(int device);
+    bool createResources(int device, uint32_t flags);
 
     srx_ctx* m_ctx;
     std::vector<uint8_t> m_inputImage;   // decoded file, RGBA8

@@ -28,6 +28,7 @@ void ThrowIfFailed(bool ok, const char* what)
 SuperResolutionX::SuperResolutionX(uint32_t width, uint32_t height, std::wstring name) :
     DXFramework(width, height, name),
     m_vendorId(0x1002),
+    m_isFP16Supported(true),
     m_deviceIndex(0),
     m_stream(nullptr),
     m_frameIndex(0),
@@ -89,7 +90,7 @@ bool SuperResolutionX::InitTensors()
 {
     m_superResolution = make_unique<SuperResolution>();
     // fp16 tensors are always supported on gfx950 (the reference queries DirectML for this)
-    return m_superResolution->Init(m_stream, m_deviceIndex, m_vendorId, m_fileName.c_str(), true);
+    return m_superResolution->Init(m_stream, m_deviceIndex, m_vendorId, m_fileName.c_str(), m_isFP16Supported);
 }
 
 // Update frame-based values.
@@ -166,6 +167,8 @@ void SuperResolutionX::ParseCommandLineArgs(wchar_t* argv[], int argc)
     {
         if (isSwitch(i, L"warp")) m_deviceType = DEVICE_WARP;
         else if (isSwitch(i, L"uma")) m_deviceType = DEVICE_UMA;      // accepted; one kind of device here
+        else if (isSwitch(i, L"fp32")) m_isFP16Supported = false;     // the reference takes this from a device feature query
+        else if (isSwitch(i, L"nhwc")) m_vendorId = 0x10DE;            // the vendor for which the reference picks NHWC
         else if ((isSwitch(i, L"i") || isSwitch(i, L"image")) && hasValue(i))
         {
             const wstring value = argv[++i];

@@ -49,6 +49,7 @@ private:
     std::unique_ptr<SuperResolution> m_superResolution;
 
     uint32_t m_vendorId;
+    bool m_isFP16Supported;
     int m_deviceIndex;
     void* m_stream;
 

@@ -72,3 +72,15 @@ def test_failures_are_loud(workdir, tmp_path):
     os.symlink(os.path.join(ASSETS, "Sashimi128.png"), empty / "Assets" / "Sashimi128.png")
     r = run([], empty)                         # weights.bin missing -> loadWeights
     assert r.returncode != 0 and "Unable to open weight file" in r.stderr and "loadWeights" in r.stderr
+
+
+@pytest.mark.parametrize("switches", [["-fp32"], ["-fp32", "-nhwc"], ["-nhwc"]])
+def test_fp32_and_nhwc_switches(workdir, switches):
+    """-fp32 (no fp16 support) and -nhwc (the vendor for which the reference picks NHWC) run the graph
+    of generic layers; the picture stays within 1 LSB of the fused fp16 path."""
+    r = run(["-i", "Assets/Sashimi128.png", "-o", "out.png"] + switches, workdir)
+    assert r.returncode == 0, r.stderr
+    got = np.asarray(Image.open(workdir / "out.png").convert("RGB")).astype(int)
+    with S.SuperResolutionContext(128, 128) as ctx:
+        fast = ctx.run(load_png_rgba(os.path.join(ASSETS, "Sashimi128.png")))[..., :3].astype(int)
+    assert (np.abs(got - fast) <= 1).mean() >= 0.999
