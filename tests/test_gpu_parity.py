@@ -269,3 +269,25 @@ def test_frame_pipe_matches_plain_upscale():
     with S.SuperResolutionContext(W, H, batch=1) as ctx:
         with pytest.raises(S.SrxError):
             S.FramePipe(ctx, 1)                      # needs two slots
+
+
+@pytest.mark.parametrize("w,h,batch", [(1, 1, 1), (2, 3, 1), (29, 2, 1), (30, 31, 1), (31, 64, 1), (59, 5, 2), (60, 60, 1),
+                                       (61, 33, 1), (121, 7, 3), (7, 130, 1), (30, 301, 1), (95, 263, 1), (180, 90, 5)])
+def test_fused_path_edge_sizes(phases_model, w, h, batch):
+    """The two fused kernels (the product path) at sizes around their strip width (60 columns), their
+    row segments (long thin images are cut into several; segments of the 2x grid start at multiples of
+    four rows) and their four-row output blocks: against the oracle, and frame by frame."""
+    frames = [synthetic_rgba(w, h, 4000 + 7 * w + h + i) for i in range(batch)]
+    with S.SuperResolutionContext(w, h, batch=batch) as ctx:
+        assert ctx.stage_names() == ["pack_conv1_conv2_conv3_conv_up1", "conv4_conv5_conv6_add_unorm"]
+        for i, f in enumerate(frames):
+            ctx.upload_rgba8(i, f)
+        ctx.upscale()
+        ctx.sync()
+        outs = [ctx.tensor_to_image(i) for i in range(batch)]
+        ctx.sync()
+    for f, o in zip(frames, outs):
+        ref = phases_model.run(f)
+        d = np.abs(o[..., :3].astype(int) - ref[..., :3].astype(int))
+        assert d.max() <= 1 and (o[..., 3] == 255).all()
+        assert (d == 0).mean() >= 0.99
