@@ -78,7 +78,7 @@ using IC = std::integral_constant<int, N>;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // EXP: 1 = pin every epilogue piece to its MFMA gap (default: the compiler places them, which measured
-// 2 % faster); 2 = no static priority; 16 = no step barrier (timing only).
+// 2 % faster); 2 = no static priority.  Selected by env SRX_EXP (diagnostic).
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
             // ---- park row t+2
             *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
             *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
-            if ((EXP & 16) == 0) barrierLds();
+            barrierLds();
         };
 
         // steps t0 .. tLast + 3; the three steps after the last store touch only ring rows nothing
@@ -420,7 +420,7 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.clock = clockProbeBuffer(probe, int(grid.x));
     switch (exp)
     {
-        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(16)
+        SRX_HR_CASE(1) SRX_HR_CASE(2)
     default:
         SRX_HR_CASE(0)
     }

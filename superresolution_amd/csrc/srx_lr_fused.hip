@@ -134,7 +134,8 @@ __device__ __forceinline__ void mfmaChain(f32x16& acc, Frags& pre, W&& w, RD&& r
     pre = nxt;
 }
 
-// EXP: 1 = no scheduling pins; 16 = no step barrier (timing only); 32 = no static priority.
+// EXP (diagnostic build variants, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
+// epilogue pieces itself.
 template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     __syncthreads();
     if (tid < 192) reinterpret_cast<float*>(smem)[tid] = p.bias[tid];
 
-    const auto stepBarrier = [] { if (!(EXP & 16)) barrierLds(); };
+    const auto stepBarrier = [] { barrierLds(); };
 
     const int perFrame = p.strips * p.segs;
     for (TileWalk tw(p.numItems); tw.valid(); tw.next())
@@ -234,7 +235,6 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             unsigned d[8];
             const auto finish = [&](auto kk, const f32x16& acc, int row, int T, bool rowValid) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr ((EXP & 8) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
                 if constexpr (K >= 2 && K <= 14 && (K - 2) % 4 == 0)
                 {
                     constexpr int g = (K - 2) / 4;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 {
                     // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        a4f + (2 * row + py) * rowBytes, 0, (rowValid && !(EXP & 2)) ? int(rowBytes) : 0, 0x00020000);
+                        a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T]), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4], d[5], d[6], d[7]}, rs, int(laneSt[T] + 32u), 0, 0);
                 }
@@ -318,7 +318,6 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             f16x4 v;
             const auto finish = [&](auto kk, const f32x16& acc, int row, int T) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr ((EXP & 4) != 0) { if constexpr (K == 2) asm volatile("" ::"v"(acc)); return; }
                 if constexpr (K >= 2 && K <= 30 && (K - 2) % 8 == 0)
                 {
                     const bool inside = colInside[T] && row >= 0 && row < p.height;
@@ -378,7 +377,6 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             f16x4 v;
             const auto finish = [&](auto kk, const f32x16& acc, int row, int T, int half) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr ((EXP & 4) != 0) { if constexpr (K == 1) asm volatile("" ::"v"(acc)); return; }
                 if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
                 {
                     const bool inside = colInside[T] && row >= 0 && row < p.height;
@@ -563,7 +561,7 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     }
     switch (exp)
     {
-        SRX_LR_CASE(1) SRX_LR_CASE(16) SRX_LR_CASE(32) SRX_LR_CASE(2) SRX_LR_CASE(4) SRX_LR_CASE(8) SRX_LR_CASE(12) SRX_LR_CASE(6)
+        SRX_LR_CASE(1)
     default:
         SRX_LR_CASE(0)
     }
