@@ -67,6 +67,7 @@ struct srx_ctx
     float* bias[srx::kNumConvLayers] = {};
     uint16_t* wpk6Rows16 = nullptr;          // conv6 as row-streaming 16x16x32 fragments (fused kernel)
     uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
+    uint16_t* wpkK32[4] = {};                // conv2, conv3, conv_up1 phases as 16x16x32 fragments (fused kernel), by layer
     float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
 
@@ -145,6 +146,16 @@ srx_status uploadWeights(srx_ctx* c)
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         c->wpk6Rows16 = static_cast<uint16_t*>(d);
+    }
+    for (int l = 1; l <= 3; ++l)
+    {
+        const uint32_t* sz = kConvLayers[l].sizes;
+        const std::vector<uint16_t> packed = l == 3 ? PackConvUp1PhasesK32(c->folded.filter[l])
+                                                    : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]));
+        void* d = nullptr;
+        if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
+        SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        c->wpkK32[l] = static_cast<uint16_t*>(d);
     }
     {
         const std::vector<uint16_t> packed = PackConv1Rows8(c->folded.filter[0]);
@@ -351,9 +362,9 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
         ll.image = frameOffset(c->input, first);
         ll.a4 = c->tensor[SRX_T_CONV_UP1];
         ll.wpk1 = c->wpk1Rows8;
-        ll.wpk2 = c->wpk[1];
-        ll.wpk3 = c->wpk[2];
-        ll.wpkUp1 = c->wpk[3];
+        ll.wpk2 = c->wpkK32[1];
+        ll.wpk3 = c->wpkK32[2];
+        ll.wpkUp1 = c->wpkK32[3];
         ll.bias = c->biasLrFused;
         ll.width = W;
         ll.height = H;

@@ -2,16 +2,17 @@
 //
 // One workgroup of eight waves walks a strip of kLrStrip low-resolution columns
 // downwards, one row per step, keeping rolling windows of the packed input and
-// of the conv1 / conv2 / conv3 activations in LDS rings (121 KB).  Nothing but the
+// of the conv1 / conv2 / conv3 activations in LDS rings (135 KB).  Nothing but the
 // 8-bit input image is read from HBM and nothing but conv_up1's output is
 // written.  Every wave keeps the filter fragments of its share resident in VGPRs
-// and runs chains of v_mfma_f32_32x32x16_f16 over 32-pixel tiles, one 1-KiB
-// ds_read_b128 of activations per MFMA:
-//     waves 0-3  conv_up1, output phase = wave   2 chains of 36 MFMAs per step
-//     waves 4-5  conv3, 32 of the 64 outputs     2 chains of 36
-//     wave  6    conv2, all 64 outputs           4 chains of 18
-//     wave  7    conv1 + the input row loader    3 chains of 10
-// Waves w and w+4 share a SIMD, so every SIMD issues 144 MFMAs per step (102 for
+// and runs chains of MFMAs over tiles of 32 pixels x 32 outputs, one 1-KiB
+// ds_read_b128 of activations per 32 cycles of MFMA (v_mfma_f32_16x16x32_f16, four 16 x 16
+// accumulators per tile; conv1 uses v_mfma_f32_32x32x16_f16):
+//     waves 0-3  conv_up1, output phase = wave   2 chains of 72 MFMAs per step
+//     waves 4-5  conv3, 32 of the 64 outputs     2 chains of 72
+//     wave  6    conv2, all 64 outputs           4 chains of 36
+//     wave  7    conv1 + the input row loader    3 chains of 10 (32x32x16)
+// Waves w and w+4 share a SIMD, so every SIMD has 4608 MFMA cycles of work per step (3264 on
 // the last pair).
 //
 // Software pipeline.  A chain's results are converted and stored while the NEXT
@@ -49,14 +50,15 @@ constexpr int kLrThreads = 512;
 constexpr int kLrStrip = 60;
 
 constexpr int kX0Row = 104 * 8;                 // 104 RGB0 pixels of 4 halfs
-constexpr int kA1Stride = 80, kA1Row = 66 * kA1Stride;
-constexpr int kA2Stride = 144, kA2Row = 66 * kA2Stride;
+// pixel strides that make the 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
+constexpr int kA1Stride = 96, kA1Row = 66 * kA1Stride;
+constexpr int kA2Stride = 160, kA2Row = 66 * kA2Stride;
 constexpr int kBiasUp = 0, kBiasC3 = 32, kBiasC2 = 96, kBiasC1 = 160;   // floats into the bias table
 constexpr int kX0Off = 192 * 4;
 constexpr int kA1Off = kX0Off + 8 * kX0Row;     // x0: 8 slots, a1: 4 slots, a2 and a3: 5 slots
 constexpr int kA2Off = kA1Off + 4 * kA1Row;
 constexpr int kA3Off = kA2Off + 5 * kA2Row;
-constexpr int kLrSmem = kA3Off + 5 * kA2Row;    // 123584
+constexpr int kLrSmem = kA3Off + 5 * kA2Row;    // 138368
 constexpr int kAhead = 4;                       // LDS reads in flight ahead of their MFMA
 
 struct LrParams
@@ -107,6 +109,21 @@ __device__ __forceinline__ f16x4 reluHalf4(const f32x16& acc, int g)
     return __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
 }
 
+__device__ __forceinline__ f16x4 reluHalf4(const f32x4& acc)
+{
+    const f16x4 v = to_half4(acc[0], acc[1], acc[2], acc[3]);
+    return __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
+}
+
+// Initial accumulators of a 32-pixel x 32-output tile held as four 16 x 16 tiles (index = 2 * pixel
+// half + output half): lane group q holds outputs 4q .. 4q+3 of an output half.
+__device__ __forceinline__ void biasAcc16(const char* smem, int tableOff, int q, f32x4 (&acc)[4])
+{
+    const float* t = reinterpret_cast<const float*>(smem) + tableOff + 4 * q;
+    acc[0] = acc[2] = *reinterpret_cast<const f32x4*>(t);
+    acc[1] = acc[3] = *reinterpret_cast<const f32x4*>(t + 16);
+}
+
 // The first kAhead activation fragments of a chain, fetched while the chain before it runs.
 struct Frags
 {
@@ -134,6 +151,39 @@ __device__ __forceinline__ void mfmaChain(f32x16& acc, Frags& pre, W&& w, RD&& r
     pre = nxt;
 }
 
+// The same for v_mfma_f32_16x16x32_f16 on a tile of 32 pixels x 32 outputs: NK K-steps of 32 input
+// channels, each with two activation fragments (16-pixel halves, reads 2k and 2k+1) and two filter
+// fragments w(k, output half), four MFMAs into four 16 x 16 accumulators.  piece(k) follows K-step k.
+// The chip holds a higher clock on this MFMA shape than on 32x32x16 at equal work.
+template <int NK, bool PIN, class W, class RD, class RDN, class PC>
+__device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, RD&& rd, RDN&& rdNext, PC&& piece)
+{
+    constexpr int N = 2 * NK;
+    f16x8 bq[N];
+    Frags nxt;
+    forEach<NK>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        forEach<2>([&](auto hh) {
+            constexpr int R = 2 * K + decltype(hh)::value;
+            if constexpr (R + kAhead < N) bq[R + kAhead] = rd(IC<R + kAhead>{});
+            else nxt.v[R + kAhead - N] = rdNext(IC<R + kAhead - N>{});
+        });
+        const auto frag = [&](auto rr) -> f16x8 {
+            constexpr int R = decltype(rr)::value;
+            if constexpr (R < kAhead) return pre.v[R];
+            else return bq[R];
+        };
+        const f16x8 b0 = frag(IC<2 * K>{}), b1 = frag(IC<2 * K + 1>{});
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b0, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b1, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b1, acc[3], 0, 0, 0);
+        piece(kk);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    });
+    pre = nxt;
+}
+
 // EXP (diagnostic build variants, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
 // epilogue pieces itself.
 template <int EXP>
@@ -146,7 +196,8 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int px = lane & 31, h = lane >> 5;
+    const int px = lane & 31, h = lane >> 5;      // 32x32x16 fragment coordinates (conv1)
+    const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates
     const int role = wave < 4 ? 0 : (wave < 6 ? 1 : (wave == 6 ? 2 : 3));
 
     // this wave's filter fragments, resident for the whole kernel
@@ -219,89 +270,96 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // ---- conv_up1, phase `wave`: row ru at step ru + 8, rows Y0 .. Y1-1, and one more step
             // to finish the last tile
             const int py = wave >> 1, pxp = wave & 1;
-            const int laneRd = kA3Off + px * kA2Stride + h * 16;       // + tile * 32 * kA2Stride + tap offsets
-            // byte offset of this lane's 16 B within an a4 row, per tile; lanes that own no pixel get an
-            // offset no buffer descriptor covers, so their stores are dropped
-            unsigned laneSt[2];
+            const int laneRd = kA3Off + p16 * kA2Stride + q * 16;      // + pixel and tap offsets
+            // A lane ends up with 8 consecutive channels of one pixel (16 B of an a4 row): channels
+            // 0-7, 16-23, 8-15, 24-31 for q = 0 .. 3.  Lanes that own no pixel get an offset no buffer
+            // descriptor covers, so their stores are dropped.
+            unsigned laneSt[4];
 #pragma unroll
-            for (int T = 0; T < 2; ++T)
+            for (int T = 0; T < 4; ++T)        // T = 16-pixel quarter of the 64-pixel row
             {
-                const int i = T * 32 + px, col = X0 + i;
-                laneSt[T] = (i < kLrStrip && col < p.width) ? unsigned((2 * col + pxp) * 64 + h * 16) : 0xC0000000u;
+                const int i = T * 16 + p16, col = X0 + i;
+                laneSt[T] = (i < kLrStrip && col < p.width)
+                                ? unsigned((2 * col + pxp) * 64 + ((q & 1) * 32 + (q >> 1) * 16)) : 0xC0000000u;
             }
             const long rowBytes = long(p.a4.pitch) * 64;
             char* a4f = reinterpret_cast<char*>(p.a4.base + f * p.a4.frame);
-            // finish a tile: ReLU, fp16, widen to 8 consecutive channels per lane, two 16-B stores
-            unsigned d[8];
-            const auto finish = [&](auto kk, const f32x16& acc, int row, int T, bool rowValid) {
+            // finish a 32-pixel tile: ReLU, fp16, widen to 8 consecutive channels per lane, one 16-B store per
+            // 16-pixel half
+            unsigned d[4];
+            const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32, bool rowValid) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K >= 2 && K <= 14 && (K - 2) % 4 == 0)
+                if constexpr (K == 1 || K == 9)
                 {
-                    constexpr int g = (K - 2) / 4;
-                    const f16x4 v = reluHalf4(acc, g);
-                    const uint2 u = *reinterpret_cast<const uint2*>(&v);
-                    d[2 * g] = u.x;
-                    d[2 * g + 1] = u.y;
+                    constexpr int half = K == 1 ? 0 : 1;
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                    {
+                        const f16x4 v = reluHalf4(acc[half * 2 + ch]);
+                        const uint2 u = *reinterpret_cast<const uint2*>(&v);
+                        d[2 * ch] = u.x;
+                        d[2 * ch + 1] = u.y;
+                    }
                 }
-                if constexpr (K == 18 || K == 22)
+                if constexpr (K == 5 || K == 13)
                 {
-                    // after the half-wave swaps a lane holds 8 consecutive channels
-                    constexpr int pair = (K - 18) / 4;
+                    constexpr int half = K == 5 ? 0 : 1;
+                    // rows of 16 lanes: odd rows of the first operand swap with even rows of the second, after
+                    // which a lane holds 8 consecutive channels
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
                     {
-                        const auto r = __builtin_amdgcn_permlane32_swap(d[4 * pair + k], d[4 * pair + 2 + k], false, false);
-                        d[4 * pair + k] = r[0];
-                        d[4 * pair + 2 + k] = r[1];
+                        const auto r = __builtin_amdgcn_permlane16_swap(d[k], d[2 + k], false, false);
+                        d[k] = r[0];
+                        d[2 + k] = r[1];
                     }
-                }
-                if constexpr (K == 26)
-                {
                     // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                         a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T]), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4], d[5], d[6], d[7]}, rs, int(laneSt[T] + 32u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T32 * 2 + half]), 0, 0);
                 }
             };
-            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                constexpr int K = decltype(kk)::value;
-                constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+            // read r of a chain: K-step r / 2 = (tap, channel half), 16-pixel half r % 2 of the 32-pixel tile
+            const auto rdT = [&](auto rr, int T32, int c0, int c1, int c2) -> f16x8 {
+                constexpr int R = decltype(rr)::value;
+                constexpr int k = R / 2, half = R % 2, tap = k / 2, kc = k % 2, i = tap / 3, j = tap % 3;
                 const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+                return *reinterpret_cast<const f16x8*>(smem + b + (T32 * 32 + half * 16 + j) * kA2Stride + kc * 64);
             };
-            const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+            const auto w = [&](auto kk, auto hh) { return wreg[decltype(kk)::value * 2 + decltype(hh)::value]; };
 
             int t = t0;
             for (; t < Y0 + 8; ++t) stepBarrier();
-            f32x16 accA = biasAcc(smem, kBiasUp, h), accB = accA;
+            f32x4 accA[4], accB[4];
+            biasAcc16(smem, kBiasUp, q, accA);
+            biasAcc16(smem, kBiasUp, q, accB);
             Frags pre;
             {
                 const int b0 = laneRd + slot5(Y0 - 1) * kA2Row;
-                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b0, b0, b0); });
             }
             for (int ru = Y0; ru < Y1; ++ru, ++t)
             {
                 const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
                           b2 = laneRd + slot5(ru + 1) * kA2Row;
                 // tile 0; finishes tile 1 of the previous row
-                mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) {
-                                       finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
-                                       if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasUp, h);
-                                   });
+                mfmaChain16<18, PIN>(accA, pre, w, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                                     [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                     [&](auto kk) {
+                                         finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
+                                         if constexpr (decltype(kk)::value == 15) biasAcc16(smem, kBiasUp, q, accB);
+                                     });
                 // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
                 // first fragments come from row ru (slot b1)
-                mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                   [&](auto kk) {
-                                       finish(kk, accA, ru, 0, true);
-                                       if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasUp, h);
-                                   });
+                mfmaChain16<18, PIN>(accB, pre, w, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                     [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
+                                     [&](auto kk) {
+                                         finish(kk, accA, ru, 0, true);
+                                         if constexpr (decltype(kk)::value == 15) biasAcc16(smem, kBiasUp, q, accA);
+                                     });
                 stepBarrier();
             }
-            forEach<27>([&](auto kk) { finish(kk, accB, Y1 - 1, 1, true); });
+            forEach<14>([&](auto kk) { finish(kk, accB, Y1 - 1, 1, true); });
             stepBarrier();
             for (++t; t <= tEnd; ++t) stepBarrier();
         }
@@ -310,58 +368,65 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // ---- conv3, outputs 32 * (wave - 4) ..: row r3 at step r3 + 5, rows Y0-1 .. Y1, and one more
             // step to finish the last tile
             const int nt = wave - 4;
-            const int laneRd = kA2Off + px * kA2Stride + h * 16;
-            const int laneWr = kA3Off + px * kA2Stride + nt * 64 + h * 8;
-            bool colInside[2];
+            const int laneRd = kA2Off + p16 * kA2Stride + q * 16;
+            const int laneWr = kA3Off + p16 * kA2Stride + nt * 64 + q * 8;
+            bool colInside[4];
 #pragma unroll
-            for (int T = 0; T < 2; ++T) colInside[T] = X0 - 1 + T * 32 + px >= 0 && X0 - 1 + T * 32 + px < p.width;
+            for (int T = 0; T < 4; ++T) colInside[T] = X0 - 1 + T * 16 + p16 >= 0 && X0 - 1 + T * 16 + p16 < p.width;
             f16x4 v;
-            const auto finish = [&](auto kk, const f32x16& acc, int row, int T) {
+            // accumulator a = (16-pixel half a >> 1, 16-output half a & 1) of the 32 x 32 tile
+            const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K >= 2 && K <= 30 && (K - 2) % 8 == 0)
+                if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
                 {
-                    const bool inside = colInside[T] && row >= 0 && row < p.height;
-                    v = reluHalf4(acc, (K - 2) / 8);
+                    constexpr int a = (K - 1) / 4;
+                    const bool inside = colInside[T32 * 2 + (a >> 1)] && row >= 0 && row < p.height;
+                    v = reluHalf4(acc[a]);
                     v = inside ? v : f16x4{0, 0, 0, 0};
                 }
-                if constexpr (K >= 6 && K <= 30 && (K - 6) % 8 == 0)
-                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + ((K - 6) / 8) * 16) = v;
+                if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
+                {
+                    constexpr int a = (K - 3) / 4;
+                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + (a >> 1) * 16) * kA2Stride + (a & 1) * 32) = v;
+                }
             };
-            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                constexpr int K = decltype(kk)::value;
-                constexpr int i = K / 12, j = (K / 4) % 3, cc = K % 4;
+            const auto rdT = [&](auto rr, int T32, int c0, int c1, int c2) -> f16x8 {
+                constexpr int R = decltype(rr)::value;
+                constexpr int k = R / 2, half = R % 2, tap = k / 2, kc = k % 2, i = tap / 3, j = tap % 3;
                 const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA2Stride + j * kA2Stride + cc * 32);
+                return *reinterpret_cast<const f16x8*>(smem + b + (T32 * 32 + half * 16 + j) * kA2Stride + kc * 64);
             };
-            const auto w = [&](auto kk) { return wreg[decltype(kk)::value]; };
+            const auto w = [&](auto kk, auto hh) { return wreg[decltype(kk)::value * 2 + decltype(hh)::value]; };
 
             int t = t0;
             for (; t < Y0 + 4; ++t) stepBarrier();
-            f32x16 accA = biasAcc(smem, kBiasC3 + nt * 32, h), accB = accA;
+            f32x4 accA[4], accB[4];
+            biasAcc16(smem, kBiasC3 + nt * 32, q, accA);
+            biasAcc16(smem, kBiasC3 + nt * 32, q, accB);
             Frags pre;
             {
                 const int b0 = laneRd + slot5(Y0 - 2) * kA2Row;
-                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b0, b0, b0); });
             }
             for (int r3 = Y0 - 1; r3 <= Y1; ++r3, ++t)
             {
                 const int b0 = laneRd + slot5(r3 - 1) * kA2Row, b1 = laneRd + slot5(r3) * kA2Row,
                           b2 = laneRd + slot5(r3 + 1) * kA2Row;
-                mfmaChain<36, PIN>(accA, pre, w, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) {
-                                       finish(kk, accB, r3 - 1, 1);
-                                       if constexpr (decltype(kk)::value == 31) accB = biasAcc(smem, kBiasC3 + nt * 32, h);
-                                   });
-                mfmaChain<36, PIN>(accB, pre, w, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                   [&](auto kk) {
-                                       finish(kk, accA, r3, 0);
-                                       if constexpr (decltype(kk)::value == 31) accA = biasAcc(smem, kBiasC3 + nt * 32, h);
-                                   });
+                mfmaChain16<18, PIN>(accA, pre, w, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                                     [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                     [&](auto kk) {
+                                         finish(kk, accB, r3 - 1, 1);
+                                         if constexpr (decltype(kk)::value == 16) biasAcc16(smem, kBiasC3 + nt * 32, q, accB);
+                                     });
+                mfmaChain16<18, PIN>(accB, pre, w, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                     [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
+                                     [&](auto kk) {
+                                         finish(kk, accA, r3, 0);
+                                         if constexpr (decltype(kk)::value == 16) biasAcc16(smem, kBiasC3 + nt * 32, q, accA);
+                                     });
                 stepBarrier();
             }
-            forEach<31>([&](auto kk) { finish(kk, accB, Y1, 1); });
+            forEach<16>([&](auto kk) { finish(kk, accB, Y1, 1); });
             stepBarrier();
             for (++t; t <= tEnd; ++t) stepBarrier();
         }
@@ -369,72 +434,79 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         {
             // ---- conv2, all 64 outputs as four chains (tile, half of the outputs): row r2 at step r2 + 2,
             // rows Y0-2 .. Y1+1, and one more step to finish the last chain
-            const int laneRd = kA1Off + px * kA1Stride + h * 16;
-            const int laneWr = kA2Off + px * kA2Stride + h * 8;
-            bool colInside[2];
+            const int laneRd = kA1Off + p16 * kA1Stride + q * 16;
+            const int laneWr = kA2Off + p16 * kA2Stride + q * 8;
+            bool colInside[4];
 #pragma unroll
-            for (int T = 0; T < 2; ++T) colInside[T] = X0 - 2 + T * 32 + px >= 0 && X0 - 2 + T * 32 + px < p.width;
+            for (int T = 0; T < 4; ++T) colInside[T] = X0 - 2 + T * 16 + p16 >= 0 && X0 - 2 + T * 16 + p16 < p.width;
             f16x4 v;
-            const auto finish = [&](auto kk, const f32x16& acc, int row, int T, int half) {
+            const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32, int oTile) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
+                if constexpr (K <= 6 && K % 2 == 0)
                 {
-                    const bool inside = colInside[T] && row >= 0 && row < p.height;
-                    v = reluHalf4(acc, (K - 1) / 4);
+                    constexpr int a = K / 2;
+                    const bool inside = colInside[T32 * 2 + (a >> 1)] && row >= 0 && row < p.height;
+                    v = reluHalf4(acc[a]);
                     v = inside ? v : f16x4{0, 0, 0, 0};
                 }
-                if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
-                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + T * 32 * kA2Stride + half * 64 + ((K - 3) / 4) * 16) = v;
+                if constexpr (K <= 7 && K % 2 == 1)
+                {
+                    constexpr int a = K / 2;
+                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + (a >> 1) * 16) * kA2Stride + oTile * 64 + (a & 1) * 32) = v;
+                }
             };
-            const auto rdT = [&](auto kk, int T, int c0, int c1, int c2) -> f16x8 {
-                constexpr int K = decltype(kk)::value;
-                constexpr int i = K / 6, j = (K / 2) % 3, cc = K % 2;
+            // read r of a chain: K-step r / 2 = tap (32 input channels), 16-pixel half r % 2
+            const auto rdT = [&](auto rr, int T32, int c0, int c1, int c2) -> f16x8 {
+                constexpr int R = decltype(rr)::value;
+                constexpr int tap = R / 2, half = R % 2, i = tap / 3, j = tap % 3;
                 const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
-                return *reinterpret_cast<const f16x8*>(smem + b + T * 32 * kA1Stride + j * kA1Stride + cc * 32);
+                return *reinterpret_cast<const f16x8*>(smem + b + (T32 * 32 + half * 16 + j) * kA1Stride);
             };
-            const auto wLo = [&](auto kk) { return wreg[decltype(kk)::value]; };
-            const auto wHi = [&](auto kk) { return wreg[18 + decltype(kk)::value]; };
+            const auto wLo = [&](auto kk, auto hh) { return wreg[decltype(kk)::value * 2 + decltype(hh)::value]; };
+            const auto wHi = [&](auto kk, auto hh) { return wreg[18 + decltype(kk)::value * 2 + decltype(hh)::value]; };
 
             int t = t0;
             for (; t < Y0; ++t) stepBarrier();
-            f32x16 acc0 = biasAcc(smem, kBiasC2, h), acc1 = biasAcc(smem, kBiasC2 + 32, h);
+            f32x4 acc0[4], acc1[4];
+            biasAcc16(smem, kBiasC2, q, acc0);
+            biasAcc16(smem, kBiasC2 + 32, q, acc1);
             Frags pre;
             {
                 const int b0 = laneRd + ((Y0 - 3) & 3) * kA1Row;
-                forEach<kAhead>([&](auto kk) { pre.v[decltype(kk)::value] = rdT(kk, 0, b0, b0, b0); });
+                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b0, b0, b0); });
             }
             for (int r2 = Y0 - 2; r2 <= Y1 + 1; ++r2, ++t)
             {
                 const int b0 = laneRd + ((r2 - 1) & 3) * kA1Row, b1 = laneRd + (r2 & 3) * kA1Row,
                           b2 = laneRd + ((r2 + 1) & 3) * kA1Row;
                 // (tile 0, outputs 0-31); finishes (tile 1, outputs 32-63) of the previous row
-                mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                   [&](auto kk) {
-                                       finish(kk, acc1, r2 - 1, 1, 1);
-                                       if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
-                                   });
-                mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 0, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) {
-                                       finish(kk, acc0, r2, 0, 0);
-                                       if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
-                                   });
-                mfmaChain<18, PIN>(acc0, pre, wLo, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) {
-                                       finish(kk, acc1, r2, 0, 1);
-                                       if constexpr (decltype(kk)::value == 15) acc1 = biasAcc(smem, kBiasC2 + 32, h);
-                                   });
-                mfmaChain<18, PIN>(acc1, pre, wHi, [&](auto kk) { return rdT(kk, 1, b0, b1, b2); },
-                                   [&](auto kk) { return rdT(kk, 0, b1, b1, b1); },
-                                   [&](auto kk) {
-                                       finish(kk, acc0, r2, 1, 0);
-                                       if constexpr (decltype(kk)::value == 15) acc0 = biasAcc(smem, kBiasC2, h);
-                                   });
+                mfmaChain16<9, PIN>(acc0, pre, wLo, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                                    [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                                    [&](auto kk) {
+                                        finish(kk, acc1, r2 - 1, 1, 1);
+                                        if constexpr (decltype(kk)::value == 8) biasAcc16(smem, kBiasC2 + 32, q, acc1);
+                                    });
+                mfmaChain16<9, PIN>(acc1, pre, wHi, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                                    [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                    [&](auto kk) {
+                                        finish(kk, acc0, r2, 0, 0);
+                                        if constexpr (decltype(kk)::value == 8) biasAcc16(smem, kBiasC2, q, acc0);
+                                    });
+                mfmaChain16<9, PIN>(acc0, pre, wLo, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                    [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                    [&](auto kk) {
+                                        finish(kk, acc1, r2, 0, 1);
+                                        if constexpr (decltype(kk)::value == 8) biasAcc16(smem, kBiasC2 + 32, q, acc1);
+                                    });
+                mfmaChain16<9, PIN>(acc1, pre, wHi, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                                    [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
+                                    [&](auto kk) {
+                                        finish(kk, acc0, r2, 1, 0);
+                                        if constexpr (decltype(kk)::value == 8) biasAcc16(smem, kBiasC2, q, acc0);
+                                    });
                 stepBarrier();
             }
-            forEach<16>([&](auto kk) { finish(kk, acc1, Y1 + 1, 1, 1); });
+            forEach<8>([&](auto kk) { finish(kk, acc1, Y1 + 1, 1, 1); });
             stepBarrier();
             for (++t; t <= tEnd; ++t) stepBarrier();
         }

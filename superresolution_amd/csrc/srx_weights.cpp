@@ -463,6 +463,38 @@ std::vector<uint16_t> ConvUp1PhaseFilters(const std::vector<uint16_t>& oihw)
     return out;
 }
 
+std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout, int cin)
+{
+    const int tiles = (cout + 31) / 32, kchunks = cin / 32, ksteps = 9 * kchunks;
+    std::vector<uint16_t> out(size_t(tiles) * ksteps * 2 * 64 * 8, 0);
+    for (int t = 0; t < tiles; ++t)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int kc = 0; kc < kchunks; ++kc)
+                for (int half = 0; half < 2; ++half)
+                    for (int lane = 0; lane < 64; ++lane)
+                    {
+                        const int o = t * 32 + half * 16 + (lane & 15), q = lane >> 4;
+                        if (o >= cout) continue;
+                        const size_t dst = (((size_t(t) * ksteps + tap * kchunks + kc) * 2 + half) * 64 + lane) * 8;
+                        for (int j = 0; j < 8; ++j) out[dst + j] = oihw[(size_t(o) * cin + kc * 32 + 8 * q + j) * 9 + tap];
+                    }
+    return out;
+}
+
+std::vector<uint16_t> PackConvUp1PhasesK32(const std::vector<uint16_t>& oihw)
+{
+    const std::vector<uint16_t> phases = ConvUp1PhaseFilters(oihw);
+    std::vector<uint16_t> out;
+    for (int p = 0; p < 4; ++p)
+    {
+        const std::vector<uint16_t> one(phases.begin() + size_t(p) * 32 * 64 * 9,
+                                        phases.begin() + size_t(p + 1) * 32 * 64 * 9);
+        const std::vector<uint16_t> packed = PackConv3x3K32(one, 32, 64);
+        out.insert(out.end(), packed.begin(), packed.end());
+    }
+    return out;
+}
+
 std::vector<uint16_t> PackConvUp1Phases(const std::vector<uint16_t>& oihw)
 {
     const std::vector<uint16_t> phases = ConvUp1PhaseFilters(oihw);
