@@ -204,8 +204,8 @@ def main():
                          "note": "achieved = FLOPs of the kernel's algorithm (conv_up1 in its four-phase 3x3 form, "
                                  "2.78x fewer MACs than the reference's direct 5x5-on-upsampled form) x 1920x1080 x "
                                  "frames per launch / HIP-event launch time; *_direct_form counts conv_up1 as the "
-                                 "reference evaluates it.  The chip holds about 1.65 GHz (not 2.4) under this MFMA "
-                                 "load: a bare LDS-fed MFMA loop of the same shape measures 1.58 PFLOP/s here "
+                                 "reference evaluates it.  The chip holds about 1.8 GHz (not 2.4) under this MFMA "
+                                 "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
         if world == 1 and not args.no_pcie_leg:
