@@ -21,7 +21,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add"]
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights"]
 
 
 class SrxError(RuntimeError):
@@ -79,6 +79,7 @@ def lib():
     L.srx_tensor_shape.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.srx_fold_weights.argtypes = [C.c_char_p, i32, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.srx_packed_weights.argtypes = [C.c_char_p, i32, vp, sz, C.POINTER(sz)]
+    L.srx_fused_weights.argtypes = [C.c_char_p, i32, vp, sz, C.POINTER(sz)]
     L.srx_num_stages.argtypes = [vp]
     L.srx_stage_name.argtypes = [vp, i32]
     L.srx_stage_name.restype = C.c_char_p
@@ -282,6 +283,17 @@ def fold_weights(layer, weights_path=None):
     _check(L.srx_fold_weights(path, layer, f.ctypes.data, f.size, b.ctypes.data if bn.value else None, b.size,
                               None, None))
     return f, (b if bn.value else None)
+
+
+def fused_weights(layer, weights_path=None):
+    """Host-only: the fragments of conv layer 0..6 as the fused kernels hold them."""
+    L = lib()
+    path = (weights_path or default_weights_path()).encode()
+    n = C.c_size_t()
+    _check(L.srx_fused_weights(path, layer, None, 0, C.byref(n)))
+    out = np.empty(n.value, np.uint16)
+    _check(L.srx_fused_weights(path, layer, out.ctypes.data, out.size, None))
+    return out
 
 
 def packed_weights(layer, weights_path=None):

@@ -726,6 +726,29 @@ srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, si
     return SRX_OK;
 }
 
+srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n)
+{
+    if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_fused_weights: bad argument");
+    srx::ML::WeightMapType weights;
+    srx::FoldedWeights folded;
+    if (!srx::LoadWeights(path, weights, false) || !srx::FoldWeights(weights, folded))
+        return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + path);
+    const uint32_t* sz = srx::kConvLayers[layer].sizes;
+    const std::vector<uint16_t> packed =
+        layer == 0 ? srx::PackConv1Rows8(folded.filter[0])
+        : layer <= 2 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]))
+        : layer == 3 ? srx::PackConvUp1PhasesK32(folded.filter[3])
+        : layer <= 5 ? srx::PackConv3x3(folded.filter[layer], int(sz[0]), int(sz[1]))
+                     : srx::PackConv6Rotating(folded.filter[6]);
+    if (n) *n = packed.size();
+    if (out)
+    {
+        if (cap < packed.size()) return fail(SRX_ERR_INVALID, "srx_fused_weights: buffer too small");
+        std::memcpy(out, packed.data(), packed.size() * 2);
+    }
+    return SRX_OK;
+}
+
 int32_t srx_num_stages(const srx_ctx* c) { return validCtx(c) ? int32_t(c->stages.size()) : 0; }
 
 const char* srx_stage_name(const srx_ctx* c, int32_t i)

@@ -134,3 +134,71 @@ def test_packed_up1_phase_filters(oracle):
             ph = np.array([[k[np.ix_(r, c)].sum() for c in groups[px]] for r in groups[py]])
             got = np.array([[(xp[y:y + 3, xx:xx + 3] * ph).sum() for xx in range(7)] for y in range(6)])
             assert np.allclose(got, direct[py::2, px::2])
+
+
+def test_fused_k32_layout():
+    """conv2 / conv3 as v_mfma_f32_16x16x32_f16 A fragments: lane (r, q) = output r of its half, channels 8q..8q+7."""
+    for li, (cout, cin) in {1: (64, 32), 2: (64, 64)}.items():
+        f, _ = S.fold_weights(li)
+        w = f.reshape(cout, cin, 9)
+        kch = cin // 32
+        p = S.fused_weights(li).reshape(cout // 32, 9 * kch, 2, 64, 8)
+        for lane in range(64):
+            r, q = lane & 15, lane >> 4
+            for tile in range(cout // 32):
+                for half in range(2):
+                    o = tile * 32 + half * 16 + r
+                    for kc in range(kch):
+                        want = w[o, kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :]           # [8, 9]
+                        got = p[tile, kc::kch, half, lane, :]                             # [9 taps, 8]
+                        assert np.array_equal(got, want.T)
+
+
+def test_fused_up1_phases_k32_match_the_32x32_packing():
+    """The four phase filters, once as 32x32x16 fragments (layer-wise kernel) and once as 16x16x32
+    fragments (fused kernel), hold the same numbers."""
+    a = S.packed_weights(3).reshape(4, -1)
+    b = S.fused_weights(3).reshape(4, 18, 2, 64, 8)
+    for ph in range(4):
+        w = _unpack3x3(a[ph], 32, 64)                       # [32, 64, 9]
+        for lane in (0, 7, 15, 16, 33, 63):
+            r, q = lane & 15, lane >> 4
+            for half in range(2):
+                for kc in range(2):
+                    assert np.array_equal(b[ph, kc::2, half, lane, :], w[half * 16 + r, kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :].T)
+
+
+def test_fused_conv6_rotating_layout():
+    """conv6 streams input rows: for input row R (rho = R mod 4) group g of the 16 MFMA rows gets filter row
+    2 (g = rho - 1), 1 (g = rho) or 0 (g = rho + 1) of output channel c = row & 3; everything else is zero."""
+    f, _ = S.fold_weights(6)
+    w = f.reshape(3, 32, 3, 3)
+    p = S.fused_weights(6).reshape(4, 3, 64, 8)
+    for rho in range(4):
+        for j in range(3):
+            for lane in range(64):
+                row, q = lane & 15, lane >> 4
+                g, c = row >> 2, row & 3
+                i = {(rho + 3) & 3: 2, rho: 1, (rho + 1) & 3: 0}.get(g)
+                want = w[c, 8 * q:8 * q + 8, i, j] if (c < 3 and i is not None) else np.zeros(8, np.uint16)
+                assert np.array_equal(p[rho, j, lane], want)
+    # summed over the three input rows that touch it, every output row gets each filter row exactly once
+    for y in range(4):
+        rows = sorted({(rho + 3) & 3: 2, rho: 1, (rho + 1) & 3: 0}[y] for rho in range(4) if y in ((rho + 3) & 3, rho, (rho + 1) & 3))
+        assert rows == [0, 1, 2]
+
+
+def test_fused_conv1_and_conv45_layouts():
+    f, _ = S.fold_weights(0)
+    w = f.reshape(32, 3, 5, 5)
+    p = S.fused_weights(0).reshape(5, 2, 64, 8)
+    for i in range(5):
+        for u in range(2):
+            for lane in (0, 9, 31, 32, 50, 63):
+                o, h = lane & 31, lane >> 5
+                for jj in range(8):
+                    tap, c = 4 * u + 2 * h + (jj >> 2), jj & 3
+                    want = w[o, c, i, tap] if (tap < 5 and c < 3) else 0
+                    assert p[i, u, lane, jj] == want
+    for li in (4, 5):
+        assert np.array_equal(S.fused_weights(li), S.packed_weights(li))
