@@ -291,3 +291,20 @@ def test_fused_path_edge_sizes(phases_model, w, h, batch):
         d = np.abs(o[..., :3].astype(int) - ref[..., :3].astype(int))
         assert d.max() <= 1 and (o[..., 3] == 255).all()
         assert (d == 0).mean() >= 0.99
+
+
+def test_uhd_input_window_matches_standalone_run():
+    """3840x2160 -> 7680x4320 (64 strips, several row segments, 2 GB of conv_up1 output): a window of the
+    result equals the same window run as its own image with a 7-pixel halo."""
+    W, H = 3840, 2160
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    with S.SuperResolutionContext(W, H) as ctx:
+        out = ctx.run(img)
+    assert out.shape == (2 * H, 2 * W, 4)
+    x0, y0, s, halo = W // 2 - 37, H // 2 + 11, 160, 7
+    sub = np.ascontiguousarray(img[y0 - halo:y0 + s + halo, x0 - halo:x0 + s + halo])
+    with S.SuperResolutionContext(s + 2 * halo, s + 2 * halo) as small:
+        o2 = small.run(sub)
+    assert np.array_equal(o2[2 * halo:2 * (halo + s), 2 * halo:2 * (halo + s)], out[2 * y0:2 * (y0 + s), 2 * x0:2 * (x0 + s)])
