@@ -207,6 +207,11 @@ typedef struct srx_pipe srx_pipe;
 srx_status srx_pipe_create(srx_ctx* ctx, uint32_t frames_per_slot, srx_pipe** out);
 srx_status srx_pipe_destroy(srx_pipe* pipe);
 uint32_t   srx_pipe_slots(const srx_pipe* pipe);
+/* Channels per pixel of the pinned buffers, 4 = RGBA8 (default) or 3 = RGB8: the
+ * loader's expansion of 3-channel data (XUSG/Advanced/XUSGTextureLoader.h:20) and
+ * SaveImage's dropped alpha (SuperResolutionX.cpp:423-443) then happen on the GPU
+ * and a quarter less data crosses PCIe.  Before the first srx_pipe_submit. */
+srx_status srx_pipe_set_channels(srx_pipe* pipe, uint32_t in_channels, uint32_t out_channels);
 srx_status srx_pipe_input(srx_pipe* pipe, uint32_t slot, uint8_t** host_rgba,
                           size_t* pitch, size_t* frame_stride);
 srx_status srx_pipe_submit(srx_pipe* pipe, uint32_t slot);

@@ -21,7 +21,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights"]
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels"]
 
 
 class SrxError(RuntimeError):
@@ -92,6 +92,7 @@ def lib():
     L.srx_pipe_slots.argtypes = [vp]
     L.srx_pipe_input.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.srx_pipe_submit.argtypes = [vp, u32]
+    L.srx_pipe_set_channels.argtypes = [vp, u32, u32]
     L.srx_pipe_wait.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     u32x4 = C.POINTER(u32 * 4)
     L.srx_layer_conv2d.argtypes = [i32, i32, vp, u32x4, vp, u32x4, vp, vp, vp]
@@ -214,11 +215,14 @@ class SuperResolutionContext:
 class FramePipe:
     """Frames in flight between host memory and one ctx: pinned buffers per slot, three streams."""
 
-    def __init__(self, ctx, frames_per_slot):
+    def __init__(self, ctx, frames_per_slot, in_channels=4, out_channels=4):
         self._ctx, self._L, self._h = ctx, ctx._L, C.c_void_p()
         _check(self._L.srx_pipe_create(ctx._h, frames_per_slot, C.byref(self._h)))
         self.frames_per_slot = frames_per_slot
         self.slots = int(self._L.srx_pipe_slots(self._h))
+        self.in_channels, self.out_channels = in_channels, out_channels
+        if (in_channels, out_channels) != (4, 4):
+            _check(self._L.srx_pipe_set_channels(self._h, in_channels, out_channels))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -239,7 +243,7 @@ class FramePipe:
         _check(self._L.srx_pipe_input(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
         n = self.frames_per_slot * stride.value
         buf = (C.c_uint8 * n).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, self._ctx.height, self._ctx.width, 4)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, self._ctx.height, self._ctx.width, self.in_channels)
 
     def submit(self, slot):
         _check(self._L.srx_pipe_submit(self._h, slot))
@@ -250,7 +254,7 @@ class FramePipe:
         _check(self._L.srx_pipe_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
         n = self.frames_per_slot * stride.value
         buf = (C.c_uint8 * n).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, 4)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, self.out_channels)
 
 
 def _sizes(v):

@@ -832,6 +832,8 @@ struct srx_pipe
     uint32_t perSlot = 0, slots = 0;
     size_t inPitch = 0, inFrame = 0, outPitch = 0, outFrame = 0;    // host layouts (tightly packed)
     std::vector<uint8_t*> hostIn, hostOut;
+    uint32_t inChannels = 4, outChannels = 4;
+    std::vector<uint8_t*> devRgbIn, devRgbOut;                       // per slot, RGB8 mode only
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;
     std::vector<hipEvent_t> evUp, evComp, evDown;
     std::vector<bool> submitted;
@@ -845,6 +847,8 @@ srx_status srx_pipe_destroy(srx_pipe* p)
         if (st) (void)hipStreamSynchronize(st);
     for (uint8_t* h : p->hostIn) if (h) (void)hipHostFree(h);
     for (uint8_t* h : p->hostOut) if (h) (void)hipHostFree(h);
+    for (uint8_t* d : p->devRgbIn) if (d) (void)hipFree(d);
+    for (uint8_t* d : p->devRgbOut) if (d) (void)hipFree(d);
     for (auto* v : {&p->evUp, &p->evComp, &p->evDown})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {p->up, p->comp, p->down})
@@ -898,6 +902,35 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out)
 
 uint32_t srx_pipe_slots(const srx_pipe* p) { return p ? p->slots : 0; }
 
+srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outChannels)
+{
+    if (!p || (inChannels != 3 && inChannels != 4) || (outChannels != 3 && outChannels != 4))
+        return fail(SRX_ERR_INVALID, "srx_pipe_set_channels: channels must be 3 (RGB8) or 4 (RGBA8)");
+    for (uint32_t s = 0; s < p->slots; ++s)
+        if (p->submitted[s]) return fail(SRX_ERR_STATE, "srx_pipe_set_channels: call it before the first srx_pipe_submit");
+    srx_ctx* c = p->ctx;
+    SRX_HIP(hipSetDevice(c->device));
+    if (inChannels == 3 && p->devRgbIn.empty())
+    {
+        p->devRgbIn.assign(p->slots, nullptr);
+        for (uint32_t s = 0; s < p->slots; ++s)
+            SRX_HIP(hipMalloc(reinterpret_cast<void**>(&p->devRgbIn[s]), size_t(c->width) * c->height * 3 * p->perSlot));
+    }
+    if (outChannels == 3 && p->devRgbOut.empty())
+    {
+        p->devRgbOut.assign(p->slots, nullptr);
+        for (uint32_t s = 0; s < p->slots; ++s)
+            SRX_HIP(hipMalloc(reinterpret_cast<void**>(&p->devRgbOut[s]), size_t(c->width) * c->height * 12 * p->perSlot));
+    }
+    p->inChannels = inChannels;
+    p->outChannels = outChannels;
+    p->inPitch = size_t(c->width) * inChannels;
+    p->inFrame = p->inPitch * c->height;
+    p->outPitch = size_t(c->width) * 2 * outChannels;
+    p->outFrame = p->outPitch * c->height * 2;
+    return SRX_OK;
+}
+
 srx_status srx_pipe_input(srx_pipe* p, uint32_t slot, uint8_t** host, size_t* pitch, size_t* frameStride)
 {
     if (!p || slot >= p->slots || !host) return fail(SRX_ERR_INVALID, "srx_pipe_input: bad pipe, slot or pointer");
@@ -920,19 +953,39 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot)
         SRX_HIP(hipStreamWaitEvent(p->up, p->evComp[slot], 0));
         SRX_HIP(hipStreamWaitEvent(p->comp, p->evDown[slot], 0));
     }
-    for (uint32_t f = 0; f < p->perSlot; ++f)
-        SRX_HIP(hipMemcpy2DAsync(c->input.base + size_t(first + f) * c->input.frame, size_t(c->input.pitch),
-                                 p->hostIn[slot] + f * p->inFrame, p->inPitch, p->inPitch, c->height,
-                                 hipMemcpyHostToDevice, p->up));
+    if (p->inChannels == 3)
+    {
+        SRX_HIP(hipMemcpy2DAsync(p->devRgbIn[slot], p->inPitch, p->hostIn[slot], p->inPitch, p->inPitch,
+                                 size_t(c->height) * p->perSlot, hipMemcpyHostToDevice, p->up));
+    }
+    else
+        for (uint32_t f = 0; f < p->perSlot; ++f)
+            SRX_HIP(hipMemcpy2DAsync(c->input.base + size_t(first + f) * c->input.frame, size_t(c->input.pitch),
+                                     p->hostIn[slot] + f * p->inFrame, p->inPitch, p->inPitch, c->height,
+                                     hipMemcpyHostToDevice, p->up));
     SRX_HIP(hipEventRecord(p->evUp[slot], p->up));
     SRX_HIP(hipStreamWaitEvent(p->comp, p->evUp[slot], 0));
+    // The channel repacking runs on the compute stream: the fused kernels are persistent and fill
+    // every CU, so a kernel on another stream would only get the GPU at an unpredictable kernel boundary.
+    if (p->inChannels == 3)
+        SRX_HIP(srx::LaunchRgbToRgba(p->devRgbIn[slot], frameOffset(c->input, first), int(c->width), int(c->height),
+                                     int(p->perSlot), p->comp));
     if (const srx_status s = srx_upscale_frames(c, first, p->perSlot, p->comp)) return s;
+    if (p->outChannels == 3)
+        SRX_HIP(srx::LaunchRgbaToRgb(frameOffset(c->output, first), p->devRgbOut[slot], int(c->width) * 2, int(c->height) * 2,
+                                     int(p->perSlot), p->comp));
     SRX_HIP(hipEventRecord(p->evComp[slot], p->comp));
     SRX_HIP(hipStreamWaitEvent(p->down, p->evComp[slot], 0));
-    for (uint32_t f = 0; f < p->perSlot; ++f)
-        SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot] + f * p->outFrame, p->outPitch,
-                                 c->output.base + size_t(first + f) * c->output.frame, size_t(c->output.pitch),
-                                 p->outPitch, size_t(c->height) * 2, hipMemcpyDeviceToHost, p->down));
+    if (p->outChannels == 3)
+    {
+        SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot], p->outPitch, p->devRgbOut[slot], p->outPitch, p->outPitch,
+                                 size_t(c->height) * 2 * p->perSlot, hipMemcpyDeviceToHost, p->down));
+    }
+    else
+        for (uint32_t f = 0; f < p->perSlot; ++f)
+            SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot] + f * p->outFrame, p->outPitch,
+                                     c->output.base + size_t(first + f) * c->output.frame, size_t(c->output.pitch),
+                                     p->outPitch, size_t(c->height) * 2, hipMemcpyDeviceToHost, p->down));
     SRX_HIP(hipEventRecord(p->evDown[slot], p->down));
     p->submitted[slot] = true;
     return SRX_OK;

@@ -93,6 +93,10 @@ struct StripPlan
 StripPlan PlanLrFused(int width, int height, int batch, int numCUs);
 StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
 
+// Channel repacking for the frame pipe's RGB8 mode (tightly packed RGB frames <-> RGBA8 image frames).
+hipError_t LaunchRgbToRgba(const uint8_t* rgb, const Image& dst, int width, int height, int batch, hipStream_t s);
+hipError_t LaunchRgbaToRgb(const Image& src, uint8_t* rgb, int width, int height, int batch, hipStream_t s);
+
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchConv(const ConvLaunch& l, int numCUs, hipStream_t s);

@@ -308,3 +308,26 @@ def test_uhd_input_window_matches_standalone_run():
     with S.SuperResolutionContext(s + 2 * halo, s + 2 * halo) as small:
         o2 = small.run(sub)
     assert np.array_equal(o2[2 * halo:2 * (halo + s), 2 * halo:2 * (halo + s)], out[2 * y0:2 * (y0 + s), 2 * x0:2 * (x0 + s)])
+
+
+@pytest.mark.parametrize("w,h", [(70, 45), (33, 21)])
+def test_frame_pipe_rgb8_buffers(w, h):
+    """RGB8 pinned buffers: the expansion to RGBA and the dropped alpha happen on the GPU."""
+    frames = [synthetic_rgba(w, h, 3100 + i) for i in range(6)]
+    with S.SuperResolutionContext(w, h) as one:
+        expect = [one.run(f) for f in frames]
+    with S.SuperResolutionContext(w, h, batch=6) as ctx, S.FramePipe(ctx, 3, in_channels=3, out_channels=3) as pipe:
+        for s in range(2):
+            buf = pipe.input(s)
+            assert buf.shape == (3, h, w, 3)
+            for k in range(3):
+                buf[k] = frames[s * 3 + k][..., :3]
+            pipe.submit(s)
+        for s in range(2):
+            out = pipe.wait(s)
+            assert out.shape == (3, 2 * h, 2 * w, 3)
+            for k in range(3):
+                assert np.array_equal(out[k], expect[s * 3 + k][..., :3])
+        with pytest.raises(S.SrxError):
+            from superresolution_amd._capi import _check
+            _check(pipe._L.srx_pipe_set_channels(pipe._h, 4, 4))        # too late: slots were submitted
