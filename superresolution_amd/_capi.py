@@ -31,7 +31,8 @@ class SrxError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libsrx.so")
+    # SRX_LIB names another build of the library (A/B measurements)
+    return os.environ.get("SRX_LIB") or os.path.join(HERE, "libsrx.so")
 
 
 def default_weights_path():
