@@ -1,6 +1,9 @@
-// gfx950 (MI355X, CDNA4) kernels of the super-resolution path.
+// gfx950 (MI355X, CDNA4) kernels of the super-resolution path: the layer-wise kernels (one launch per
+// layer, every tensor in HBM; the per-layer parity path), the channel repacking of the frame pipe and
+// the in-kernel clock probe.  The product path runs on the two fused kernels in srx_lr_fused.hip and
+// srx_hr_fused.hip.
 //
-// Every convolution is an implicit GEMM on v_mfma_f32_32x32x16_f16 with
+// Every convolution here is an implicit GEMM on v_mfma_f32_32x32x16_f16 with
 //   A (32 x 16)  = filter fragment, rows = output channels      -> lives in VGPRs
 //   B (16 x 32)  = activations, columns = 32 consecutive pixels  -> read from LDS
 //   D (32 x 32)  = fp32 accumulators, rows = channels, columns = pixels
