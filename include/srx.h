@@ -233,6 +233,14 @@ srx_status srx_pipe_wait(srx_pipe* pipe, uint32_t slot, const uint8_t** host_rgb
  *   add        : element-wise, `out` may alias `a` or `b`
  * Asynchronous on `stream`.
  */
+/* Host-only: what the layer factory of `kind` (0 = CreateConvolutionLayer with
+ * param = filter sizes {O, I, kh, kw}; 1 = CreateUpsampleLayer with param =
+ * {scale_x, scale_y, -, -}; 2 = CreateAdditionLayer) answers for these input
+ * sizes: the output sizes, and *in_bytes / *out_bytes raised to the byte sizes
+ * of the input and output tensors if those are larger (the reference sizes its
+ * ping-pong buffers with these running maxima, Content/SuperResolution.cpp:166-168). */
+srx_status srx_layer_plan(int32_t kind, int32_t dtype, const uint32_t in_sizes[4], const uint32_t param[4],
+                          uint32_t out_sizes[4], uint64_t* in_bytes, uint64_t* out_bytes);
 srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const uint32_t in_sizes[4],
                             const void* filter, const uint32_t filter_sizes[4], const void* bias,
                             void* out, void* stream);

@@ -6,9 +6,9 @@ library is missing or the device is not a gfx950 GPU, calls raise.
 """
 from ._capi import (SrxError, SuperResolutionContext, FramePipe, lib, lib_path, ASSETS_DIR, default_weights_path,
                     FLAG_KEEP_TENSORS, FLAG_VERBOSE_WEIGHTS, FLAG_GENERIC_LAYERS, FLAG_FP32, FLAG_NHWC,
-                    layer_conv2d, layer_upsample2d, layer_add, TENSOR_NAMES, build_library,
+                    layer_conv2d, layer_upsample2d, layer_add, layer_plan, TENSOR_NAMES, build_library,
                     fold_weights, packed_weights, fused_weights)
 
 __all__ = ["SrxError", "SuperResolutionContext", "FramePipe", "lib", "lib_path", "ASSETS_DIR", "default_weights_path",
            "FLAG_KEEP_TENSORS", "FLAG_VERBOSE_WEIGHTS", "FLAG_GENERIC_LAYERS", "FLAG_FP32", "FLAG_NHWC",
-           "layer_conv2d", "layer_upsample2d", "layer_add", "TENSOR_NAMES", "build_library", "fold_weights", "packed_weights", "fused_weights"]
+           "layer_conv2d", "layer_upsample2d", "layer_add", "layer_plan", "TENSOR_NAMES", "build_library", "fold_weights", "packed_weights", "fused_weights"]

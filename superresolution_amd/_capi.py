@@ -21,7 +21,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels"]
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan"]
 
 
 class SrxError(RuntimeError):
@@ -99,6 +99,7 @@ def lib():
     L.srx_layer_conv2d.argtypes = [i32, i32, vp, u32x4, vp, u32x4, vp, vp, vp]
     L.srx_layer_upsample2d.argtypes = [i32, i32, vp, u32x4, u32, u32, i32, vp, vp]
     L.srx_layer_add.argtypes = [i32, vp, vp, vp, sz, vp]
+    L.srx_layer_plan.argtypes = [i32, i32, u32x4, u32x4, u32x4, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     for name in SYMBOLS:
         if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch", "srx_pipe_slots"):
             getattr(L, name).restype = i32
@@ -260,6 +261,15 @@ class FramePipe:
 
 def _sizes(v):
     return (C.c_uint32 * 4)(*[int(x) for x in v])
+
+
+def layer_plan(kind, dtype, in_sizes, param, in_bytes=0, out_bytes=0):
+    """Host-only: (out_sizes, in_bytes, out_bytes) the layer factory reports (kind 0 conv, 1 upsample, 2 add)."""
+    out = (C.c_uint32 * 4)()
+    ib, ob = C.c_uint64(in_bytes), C.c_uint64(out_bytes)
+    _check(lib().srx_layer_plan(kind, dtype, C.byref(_sizes(in_sizes)), C.byref(_sizes(param)), C.byref(out),
+                                C.byref(ib), C.byref(ob)))
+    return tuple(out), ib.value, ob.value
 
 
 def layer_conv2d(dtype, layout, in_ptr, in_sizes, filter_ptr, filter_sizes, bias_ptr, out_ptr, stream=None):

@@ -779,6 +779,29 @@ bool utilFor(int32_t dtype, int32_t layout, srx::ML::Util& out)
 }
 }  // namespace
 
+srx_status srx_layer_plan(int32_t kind, int32_t dtype, const uint32_t inSizes[4], const uint32_t param[4],
+                          uint32_t outSizes[4], uint64_t* inBytes, uint64_t* outBytes)
+{
+    srx::ML::Util util;
+    srx::ML::Operator op;
+    uint64_t ib = inBytes ? *inBytes : 0, ob = outBytes ? *outBytes : 0;
+    uint32_t os[4] = {};
+    bool ok = inSizes && utilFor(dtype, 0, util);
+    if (ok && kind == 0) ok = param && util.CreateConvolutionLayer(inSizes, param, true, ib, ob, os, op);
+    else if (ok && kind == 1) ok = param && util.CreateUpsampleLayer(inSizes, ib, ob, os, op, param[0], param[1]);
+    else if (ok && kind == 2)
+    {
+        ok = util.CreateAdditionLayer(inSizes, op);
+        if (ok) std::memcpy(os, inSizes, sizeof(os));
+    }
+    else ok = false;
+    if (!ok) return fail(SRX_ERR_INVALID, "srx_layer_plan: the layer factory rejected these sizes");
+    if (outSizes) std::memcpy(outSizes, os, sizeof(os));
+    if (inBytes) *inBytes = ib;
+    if (outBytes) *outBytes = ob;
+    return SRX_OK;
+}
+
 srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const uint32_t inSizes[4], const void* filter,
                             const uint32_t filterSizes[4], const void* bias, void* out, void* stream)
 {

@@ -202,3 +202,31 @@ def test_fused_conv1_and_conv45_layouts():
                     assert p[i, u, lane, jj] == want
     for li in (4, 5):
         assert np.array_equal(S.fused_weights(li), S.packed_weights(li))
+
+
+def test_layer_factories_reproduce_the_reference_buffer_plan():
+    """createResources (Content/SuperResolution.cpp:172-275) walks the layers with running maxima of the
+    input / output byte sizes; at 1920x1080 fp16 that gives the two ping-pong buffers of 0.53 and 1.06 GB."""
+    P = 1920 * 1080
+    sizes, ib, ob = (1, 3, 1080, 1920), 0, 0
+    out0, ib, ob = S.layer_plan(1, 0, sizes, (2, 2, 0, 0), ib, ob)
+    assert out0 == (1, 3, 2160, 3840)
+    cur = sizes
+    filters = [(32, 3, 5, 5), (64, 32, 3, 3), (64, 64, 3, 3), (32, 64, 5, 5), (32, 32, 3, 3), (32, 32, 3, 3), (3, 32, 3, 3)]
+    for li, f in enumerate(filters):
+        if li == 3:
+            cur, ib, ob = S.layer_plan(1, 0, cur, (2, 2, 0, 0), ib, ob)
+            assert cur == (1, 64, 2160, 3840)
+        cur, ib, ob = S.layer_plan(0, 0, cur, f, ib, ob)
+        assert cur[1] == f[0] and cur[2:] == (2160, 3840) if li >= 3 else cur[2:] == (1080, 1920)
+    assert S.layer_plan(2, 0, cur, (0, 0, 0, 0))[0] == (1, 3, 2160, 3840)
+    assert ib == 64 * 4 * P * 2          # the upsampled conv3 tensor feeds conv_up1: 1.06 GB
+    assert ob == 64 * 4 * P * 2
+    # fp32 doubles them; a filter whose depth differs from the input channels, and zero scales, are rejected
+    assert S.layer_plan(0, 1, (1, 3, 8, 8), (4, 3, 3, 3))[1:] == (3 * 64 * 4, 4 * 64 * 4)
+    with pytest.raises(S.SrxError):
+        S.layer_plan(0, 0, (1, 3, 8, 8), (4, 2, 3, 3))
+    with pytest.raises(S.SrxError):
+        S.layer_plan(1, 0, (1, 3, 8, 8), (0, 2, 0, 0))
+    with pytest.raises(S.SrxError):
+        S.layer_plan(7, 0, (1, 3, 8, 8), (1, 1, 1, 1))
