@@ -334,13 +334,24 @@ void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream
     if (hipStreamSynchronize(s) != hipSuccess) return;
     static unsigned long long host[2 * 4096];
     if (hipMemcpy(host, probe.dev, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
-    double sum = 0, cyc = 0;
+    double sum = 0, cyc = 0, usMin = 1e30, usMax = 0, usSum = 0, ghzMin = 1e30, ghzMax = 0;
+    double xcdUs[8] = {};
     for (int b = 0; b < blocks; ++b)
     {
-        sum += double(host[2 * b]) / double(host[2 * b + 1]) * 0.1;
+        const double ghz = double(host[2 * b]) / double(host[2 * b + 1]) * 0.1, us = double(host[2 * b + 1]) * 0.01;
+        sum += ghz;
         cyc += double(host[2 * b]);
+        usSum += us;
+        usMin = us < usMin ? us : usMin;
+        usMax = us > usMax ? us : usMax;
+        ghzMin = ghz < ghzMin ? ghz : ghzMin;
+        ghzMax = ghz > ghzMax ? ghz : ghzMax;
+        xcdUs[b & 7] += us * 8 / blocks;
     }
-    fprintf(stderr, "[srx] %s: in-kernel clock %.3f GHz, %.0f cycles per workgroup\n", name, sum / blocks, cyc / blocks);
+    fprintf(stderr, "[srx] %s: in-kernel clock %.3f GHz (%.3f - %.3f), %.0f cycles per workgroup; workgroup lifetime %.0f us "
+                    "(%.0f - %.0f); by XCD:", name, sum / blocks, ghzMin, ghzMax, cyc / blocks, usSum / blocks, usMin, usMax);
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xcdUs[x]);
+    fprintf(stderr, "\n");
 }
 
 }  // namespace dev
