@@ -59,6 +59,75 @@ __global__ __launch_bounds__(256, 2) void bench(const f16x8* wsrc, const f16* ac
 #pragma unroll
         for (int r = 0; r < 16; ++r) result += acc[r];
     }
+    else if constexpr (SHAPE >= 10 && SHAPE < 30)
+    {
+        // SHAPE 10 + n: the 32x32x16 loop with n independent VALU instructions behind every MFMA
+        constexpr int n = SHAPE - 10;
+        const int px = lane & 31, h = lane >> 5;
+        const int base = px * 144 + h * 16;
+        f32x16 acc;
+        float d0 = float(lane), d1 = 1.0f, d2 = 2.0f, d3 = 3.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int it = 0; it < kIters; ++it)
+        {
+            const int off = base + (it & 7) * 4608;
+#pragma unroll
+            for (int k = 0; k < 36; ++k)
+            {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(smem + off + (k / 4) * 144 + (k % 4) * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[k], b, acc, 0, 0, 0);
+                if constexpr (n >= 1) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d0));
+                if constexpr (n >= 2) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d1));
+                if constexpr (n >= 3) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d2));
+                if constexpr (n >= 4) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d3));
+                if constexpr (n >= 5) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d0));
+                if constexpr (n >= 6) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d1));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= 0.001f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) result += acc[r];
+        result += d0 + d1 + d2 + d3;
+    }
+    else if constexpr (SHAPE >= 30)
+    {
+        // SHAPE 30 + 10*b + n: the 16x16x32 loop with n VALU instructions per MFMA on average, issued
+        // in bursts of n << b behind every (1 << b)-th MFMA
+        constexpr int n = (SHAPE - 30) % 10, b = (SHAPE - 30) / 10;
+        const int p16 = lane & 15, q = lane >> 4;
+        const int base = p16 * 160 + q * 16;
+        f32x4 acc[4];
+        float d[4] = {float(lane), 1.0f, 2.0f, 3.0f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = f32x4{0, 0, 0, 0};
+        for (int it = 0; it < kIters; ++it)
+        {
+            const int off = base + (it & 7) * 5120;
+#pragma unroll
+            for (int k = 0; k < 18; ++k)
+            {
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(smem + off + (k / 2) * 160 + (k % 2) * 64);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(smem + off + 16 * 160 + (k / 2) * 160 + (k % 2) * 64);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * k + (m & 1)], m < 2 ? b0 : b1, acc[m], 0, 0, 0);
+                    if (((4 * k + m + 1) & ((1 << b) - 1)) == 0)
+                    {
+#pragma unroll
+                        for (int v = 0; v < (n << b); ++v) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d[v & 3]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] *= 0.001f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) result += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+        result += d[0] + d[1] + d[2] + d[3];
+    }
     else if constexpr (SHAPE == 2)
     {
         // one activation fragment feeds three MFMAs (three output rows in flight): a third of the LDS reads
@@ -174,12 +243,25 @@ int main()
     CHECK(hipMalloc(&clock, blocks * 16));
     CHECK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(act, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
-    for (int round = 0; round < 3; ++round)
+    for (int round = 0; round < 1; ++round)
     {
         run<0>("32x32x16", w, act, out, clock, blocks);
         run<1>("16x16x32", w, act, out, clock, blocks);
-        run<2>("32x32 r/3", w, act, out, clock, blocks);
         run<3>("32x32 reg", w, act, out, clock, blocks);
+        run<30>("16: +0", w, act, out, clock, blocks);
+        run<31>("16: +1", w, act, out, clock, blocks);
+        run<32>("16: +2", w, act, out, clock, blocks);
+        run<33>("16: +3", w, act, out, clock, blocks);
+        run<51>("16: 4/4", w, act, out, clock, blocks);
+        run<52>("16: 8/4", w, act, out, clock, blocks);
+        run<61>("16: 8/8", w, act, out, clock, blocks);
+        run<62>("16: 16/8", w, act, out, clock, blocks);
+        run<10>("+0 VALU", w, act, out, clock, blocks);
+        run<11>("+1 VALU", w, act, out, clock, blocks);
+        run<12>("+2 VALU", w, act, out, clock, blocks);
+        run<14>("+4 VALU", w, act, out, clock, blocks);
+        run<15>("+5 VALU", w, act, out, clock, blocks);
+        run<16>("+6 VALU", w, act, out, clock, blocks);
     }
     return 0;
 }
