@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -23,6 +26,20 @@ srx_status fail(srx_status code, const std::string& msg)
     g_lastError = msg;
     return code;
 }
+
+// No C++ exception may cross the C ABI: every entry point is a function-try-block that ends in this.
+srx_status translateException() noexcept
+{
+    try
+    {
+        try { throw; }
+        catch (const std::bad_alloc&) { g_lastError = "out of host memory"; return SRX_ERR_NOMEM; }
+        catch (const std::exception& e) { g_lastError = std::string("unexpected exception: ") + e.what(); return SRX_ERR_STATE; }
+        catch (...) { g_lastError = "unexpected exception"; return SRX_ERR_STATE; }
+    }
+    catch (...) { return SRX_ERR_NOMEM; }    // not even the message could be stored
+}
+#define SRX_CATCH catch (...) { return translateException(); }
 
 #define SRX_HIP(expr)                                                                          \
     do {                                                                                       \
@@ -409,7 +426,7 @@ extern "C" {
 const char* srx_last_error(void) { return g_lastError.c_str(); }
 
 srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
-                      uint32_t in_w, uint32_t in_h, uint32_t batch, uint32_t flags)
+                      uint32_t in_w, uint32_t in_h, uint32_t batch, uint32_t flags) try
 {
     if (!out) return fail(SRX_ERR_INVALID, "srx_create: out is NULL");
     *out = nullptr;
@@ -423,7 +440,9 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (!srx::LoadWeights(weights_path, weights, (flags & SRX_FLAG_VERBOSE_WEIGHTS) != 0))
         return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + weights_path);
 
-    srx_ctx* c = new srx_ctx;
+    struct Destroy { void operator()(srx_ctx* x) const { srx_destroy(x); } };
+    std::unique_ptr<srx_ctx, Destroy> owner(new srx_ctx);      // released on success only
+    srx_ctx* c = owner.get();
     c->device = device;
     c->width = in_w;
     c->height = in_h;
@@ -431,11 +450,10 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     c->flags = flags;
     if (!srx::FoldWeights(weights, c->folded))
     {
-        delete c;
         return fail(SRX_ERR_WEIGHTS, "loadWeights: a layer's filter, scale or shift tensor is missing or has the wrong size");
     }
 
-    const auto bail = [&](srx_status s) { srx_destroy(c); return s; };
+    const auto bail = [&](srx_status s) { return s; };             // `owner` destroys the ctx
     {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)));
@@ -476,11 +494,12 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
         const hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)));
     }
-    *out = c;
+    *out = owner.release();
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_destroy(srx_ctx* c)
+srx_status srx_destroy(srx_ctx* c) try
 {
     if (!c) return SRX_OK;
     (void)hipSetDevice(c->device);
@@ -489,16 +508,18 @@ srx_status srx_destroy(srx_ctx* c)
     delete c;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_get_out_size(const srx_ctx* c, uint32_t* w, uint32_t* h)
+srx_status srx_get_out_size(const srx_ctx* c, uint32_t* w, uint32_t* h) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     if (w) *w = c->width << 1;      // Content/SuperResolution.cpp:50-51
     if (h) *h = c->height << 1;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_get_in_size(const srx_ctx* c, uint32_t* w, uint32_t* h, uint32_t* batch)
+srx_status srx_get_in_size(const srx_ctx* c, uint32_t* w, uint32_t* h, uint32_t* batch) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     if (w) *w = c->width;
@@ -506,8 +527,9 @@ srx_status srx_get_in_size(const srx_ctx* c, uint32_t* w, uint32_t* h, uint32_t*
     if (batch) *batch = c->batch;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_upload_rgba8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream)
+srx_status srx_upload_rgba8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream) try
 {
     if (!validCtx(c) || !host || frame >= c->batch || pitch < size_t(c->width) * 4)
         return fail(SRX_ERR_INVALID, "srx_upload_rgba8: bad frame, pointer or pitch");
@@ -516,8 +538,9 @@ srx_status srx_upload_rgba8(srx_ctx* c, uint32_t frame, const uint8_t* host, siz
                              size_t(c->width) * 4, c->height, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_upload_rgb8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream)
+srx_status srx_upload_rgb8(srx_ctx* c, uint32_t frame, const uint8_t* host, size_t pitch, void* stream) try
 {
     if (!validCtx(c) || !host || frame >= c->batch || pitch < size_t(c->width) * 3)
         return fail(SRX_ERR_INVALID, "srx_upload_rgb8: bad frame, pointer or pitch");
@@ -542,24 +565,27 @@ srx_status srx_upload_rgb8(srx_ctx* c, uint32_t frame, const uint8_t* host, size
     SRX_HIP(hipStreamSynchronize(st));     // the staging vector is reused by the next call
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_input_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch)
+srx_status srx_input_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch) try
 {
     if (!validCtx(c) || frame >= c->batch || !dptr) return fail(SRX_ERR_INVALID, "srx_input_device_ptr: bad argument");
     *dptr = c->input.base + size_t(frame) * c->input.frame;
     if (pitch) *pitch = size_t(c->input.pitch);
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_output_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch)
+srx_status srx_output_device_ptr(srx_ctx* c, uint32_t frame, void** dptr, size_t* pitch) try
 {
     if (!validCtx(c) || frame >= c->batch || !dptr) return fail(SRX_ERR_INVALID, "srx_output_device_ptr: bad argument");
     *dptr = c->output.base + size_t(frame) * c->output.frame;
     if (pitch) *pitch = size_t(c->output.pitch);
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
+srx_status srx_image_to_tensor(srx_ctx* c, void* stream) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
@@ -573,8 +599,9 @@ srx_status srx_image_to_tensor(srx_ctx* c, void* stream)
     if (c->stages[0] != ST_PACK) return SRX_OK;
     return launchStage(c, ST_PACK, 0, c->batch, static_cast<hipStream_t>(stream));
 }
+SRX_CATCH
 
-srx_status srx_process(srx_ctx* c, void* stream)
+srx_status srx_process(srx_ctx* c, void* stream) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
@@ -586,14 +613,16 @@ srx_status srx_process(srx_ctx* c, void* stream)
     }
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_upscale(srx_ctx* c, void* stream)
+srx_status srx_upscale(srx_ctx* c, void* stream) try
 {
     if (const srx_status s = srx_image_to_tensor(c, stream)) return s;
     return srx_process(c, stream);
 }
+SRX_CATCH
 
-srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream)
+srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream) try
 {
     if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
         return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
@@ -608,8 +637,9 @@ srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* 
     }
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t pitch, void* stream)
+srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t pitch, void* stream) try
 {
     if (!validCtx(c) || frame >= c->batch) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: bad frame");
     if (host && pitch < size_t(c->width) * 8) return fail(SRX_ERR_INVALID, "srx_tensor_to_image: pitch too small");
@@ -623,16 +653,18 @@ srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t
                                  size_t(c->width) * 8, size_t(c->height) * 2, hipMemcpyDeviceToHost, st));
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_sync(srx_ctx* c, void* stream)
+srx_status srx_sync(srx_ctx* c, void* stream) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
     SRX_HIP(hipSetDevice(c->device));
     SRX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_tensor_shape(const srx_ctx* c, int32_t id, uint32_t* ch, uint32_t* h, uint32_t* w)
+srx_status srx_tensor_shape(const srx_ctx* c, int32_t id, uint32_t* ch, uint32_t* h, uint32_t* w) try
 {
     if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT) return fail(SRX_ERR_INVALID, "srx_tensor_shape: bad tensor id");
     const TensorInfo& ti = kTensorInfo[id];
@@ -641,8 +673,9 @@ srx_status srx_tensor_shape(const srx_ctx* c, int32_t id, uint32_t* ch, uint32_t
     if (w) *w = c->width * uint32_t(ti.scale);
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, size_t bytes)
+srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, size_t bytes) try
 {
     if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT || frame >= c->batch || !out)
         return fail(SRX_ERR_INVALID, "srx_read_tensor: bad argument");
@@ -683,9 +716,10 @@ srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, si
                     raw[((y + ti.border) * t.pitch + x + ti.border) * ti.storedChannels + ch];
     return SRX_OK;
 }
+SRX_CATCH
 
 srx_status srx_fold_weights(const char* path, int32_t layer, uint16_t* filter, size_t filterCap,
-                            uint16_t* bias, size_t biasCap, size_t* filterN, size_t* biasN)
+                            uint16_t* bias, size_t biasCap, size_t* filterN, size_t* biasN) try
 {
     if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_fold_weights: bad argument");
     srx::ML::WeightMapType weights;
@@ -708,8 +742,9 @@ srx_status srx_fold_weights(const char* path, int32_t layer, uint16_t* filter, s
     }
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n)
+srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n) try
 {
     if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_packed_weights: bad argument");
     srx::ML::WeightMapType weights;
@@ -725,8 +760,9 @@ srx_status srx_packed_weights(const char* path, int32_t layer, uint16_t* out, si
     }
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n)
+srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, size_t cap, size_t* n) try
 {
     if (!path || layer < 0 || layer >= srx::kNumConvLayers) return fail(SRX_ERR_INVALID, "srx_fused_weights: bad argument");
     srx::ML::WeightMapType weights;
@@ -748,6 +784,7 @@ srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, siz
     }
     return SRX_OK;
 }
+SRX_CATCH
 
 int32_t srx_num_stages(const srx_ctx* c) { return validCtx(c) ? int32_t(c->stages.size()) : 0; }
 
@@ -758,13 +795,14 @@ const char* srx_stage_name(const srx_ctx* c, int32_t i)
 
 uint32_t srx_frames_per_launch(const srx_ctx* c) { return validCtx(c) ? std::min(c->chunk, c->batch) : 0; }
 
-srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream)
+srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream) try
 {
     if (!validCtx(c) || i < 0 || i >= int32_t(c->stages.size())) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
     SRX_HIP(hipSetDevice(c->device));
     const uint32_t count = (c->stages[size_t(i)] == ST_PACK) ? c->batch : std::min(c->chunk, c->batch);
     return launchStage(c, c->stages[size_t(i)], 0, count, static_cast<hipStream_t>(stream));
 }
+SRX_CATCH
 
 // ---------------------------------------------------------------------------
 // Generic layers on caller tensors.
@@ -780,7 +818,7 @@ bool utilFor(int32_t dtype, int32_t layout, srx::ML::Util& out)
 }  // namespace
 
 srx_status srx_layer_plan(int32_t kind, int32_t dtype, const uint32_t inSizes[4], const uint32_t param[4],
-                          uint32_t outSizes[4], uint64_t* inBytes, uint64_t* outBytes)
+                          uint32_t outSizes[4], uint64_t* inBytes, uint64_t* outBytes) try
 {
     srx::ML::Util util;
     srx::ML::Operator op;
@@ -801,9 +839,10 @@ srx_status srx_layer_plan(int32_t kind, int32_t dtype, const uint32_t inSizes[4]
     if (outBytes) *outBytes = ob;
     return SRX_OK;
 }
+SRX_CATCH
 
 srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const uint32_t inSizes[4], const void* filter,
-                            const uint32_t filterSizes[4], const void* bias, void* out, void* stream)
+                            const uint32_t filterSizes[4], const void* bias, void* out, void* stream) try
 {
     srx::ML::Util util;
     srx::ML::Operator op;
@@ -816,9 +855,10 @@ srx_status srx_layer_conv2d(int32_t dtype, int32_t layout, const void* in, const
     SRX_HIP(srx::DispatchOperator(op, in, filter, bias, out, static_cast<hipStream_t>(stream)));
     return SRX_OK;
 }
+SRX_CATCH
 
 srx_status srx_layer_upsample2d(int32_t dtype, int32_t layout, const void* in, const uint32_t inSizes[4], uint32_t scaleX,
-                                uint32_t scaleY, int32_t interpolation, void* out, void* stream)
+                                uint32_t scaleY, int32_t interpolation, void* out, void* stream) try
 {
     srx::ML::Util util;
     srx::ML::Operator op;
@@ -831,8 +871,9 @@ srx_status srx_layer_upsample2d(int32_t dtype, int32_t layout, const void* in, c
     SRX_HIP(srx::DispatchOperator(op, in, nullptr, nullptr, out, static_cast<hipStream_t>(stream)));
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_layer_add(int32_t dtype, const void* a, const void* b, void* out, size_t count, void* stream)
+srx_status srx_layer_add(int32_t dtype, const void* a, const void* b, void* out, size_t count, void* stream) try
 {
     srx::ML::Util util;
     srx::ML::Operator op;
@@ -845,6 +886,7 @@ srx_status srx_layer_add(int32_t dtype, const void* a, const void* b, void* out,
     SRX_HIP(srx::DispatchOperator(op, a, b, nullptr, out, static_cast<hipStream_t>(stream)));
     return SRX_OK;
 }
+SRX_CATCH
 
 // ---------------------------------------------------------------------------
 // Frame pipe: pinned staging buffers and three streams around srx_upscale_frames.
@@ -862,7 +904,7 @@ struct srx_pipe
     std::vector<bool> submitted;
 };
 
-srx_status srx_pipe_destroy(srx_pipe* p)
+srx_status srx_pipe_destroy(srx_pipe* p) try
 {
     if (!p) return SRX_OK;
     if (p->ctx) (void)hipSetDevice(p->ctx->device);
@@ -879,8 +921,9 @@ srx_status srx_pipe_destroy(srx_pipe* p)
     delete p;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out)
+srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) try
 {
     if (!out) return fail(SRX_ERR_INVALID, "srx_pipe_create: out is NULL");
     *out = nullptr;
@@ -922,10 +965,11 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out)
     *out = p;
     return SRX_OK;
 }
+SRX_CATCH
 
 uint32_t srx_pipe_slots(const srx_pipe* p) { return p ? p->slots : 0; }
 
-srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outChannels)
+srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outChannels) try
 {
     if (!p || (inChannels != 3 && inChannels != 4) || (outChannels != 3 && outChannels != 4))
         return fail(SRX_ERR_INVALID, "srx_pipe_set_channels: channels must be 3 (RGB8) or 4 (RGBA8)");
@@ -953,8 +997,9 @@ srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outC
     p->outFrame = p->outPitch * c->height * 2;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_pipe_input(srx_pipe* p, uint32_t slot, uint8_t** host, size_t* pitch, size_t* frameStride)
+srx_status srx_pipe_input(srx_pipe* p, uint32_t slot, uint8_t** host, size_t* pitch, size_t* frameStride) try
 {
     if (!p || slot >= p->slots || !host) return fail(SRX_ERR_INVALID, "srx_pipe_input: bad pipe, slot or pointer");
     *host = p->hostIn[slot];
@@ -962,8 +1007,9 @@ srx_status srx_pipe_input(srx_pipe* p, uint32_t slot, uint8_t** host, size_t* pi
     if (frameStride) *frameStride = p->inFrame;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot)
+srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot) try
 {
     if (!p || slot >= p->slots) return fail(SRX_ERR_INVALID, "srx_pipe_submit: bad pipe or slot");
     srx_ctx* c = p->ctx;
@@ -1013,8 +1059,9 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot)
     p->submitted[slot] = true;
     return SRX_OK;
 }
+SRX_CATCH
 
-srx_status srx_pipe_wait(srx_pipe* p, uint32_t slot, const uint8_t** host, size_t* pitch, size_t* frameStride)
+srx_status srx_pipe_wait(srx_pipe* p, uint32_t slot, const uint8_t** host, size_t* pitch, size_t* frameStride) try
 {
     if (!p || slot >= p->slots) return fail(SRX_ERR_INVALID, "srx_pipe_wait: bad pipe or slot");
     if (!p->submitted[slot]) return fail(SRX_ERR_STATE, "srx_pipe_wait: the slot was never submitted");
@@ -1025,5 +1072,6 @@ srx_status srx_pipe_wait(srx_pipe* p, uint32_t slot, const uint8_t** host, size_
     if (frameStride) *frameStride = p->outFrame;
     return SRX_OK;
 }
+SRX_CATCH
 
 }  // extern "C"
