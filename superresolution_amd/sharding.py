@@ -70,6 +70,45 @@ def upscale_tiled(rgba, tiles_x, tiles_y, device=0, halo=HALO, rank=0, world=1, 
     return out
 
 
+def gather_tiles(interiors, width, height, tiles_x, tiles_y, rank, world, dst=0, halo=HALO, device="cpu"):
+    """Optional last step of the tile partition: collect the ranks' tile interiors on rank `dst`
+    (one torch.distributed gather: RCCL over xGMI with the nccl backend and device="cuda", gloo on
+    the CPU).  `interiors` holds this rank's interiors (uint8 [2h, 2w, 4] each) in the order of
+    tiles_for_rank.  Returns the assembled uint8 [2H, 2W, 4] image on `dst`, None elsewhere.
+    Nothing on the data path needs this; it exists for consumers that want one buffer."""
+    import torch
+    import torch.distributed as dist
+    plan = tile_plan(width, height, tiles_x, tiles_y, halo)
+    per_rank = [tiles_for_rank(plan, r, world) for r in range(world)]
+    nbytes = [sum(16 * (t.x1 - t.x0) * (t.y1 - t.y0) for t in ts) for ts in per_rank]
+    if len(interiors) != len(per_rank[rank]):
+        raise ValueError("gather_tiles: one interior per tile of this rank is required")
+    flat = np.zeros(max(max(nbytes), 1), np.uint8)
+    pos = 0
+    for t, a in zip(per_rank[rank], interiors):
+        if a.shape != (2 * (t.y1 - t.y0), 2 * (t.x1 - t.x0), 4) or a.dtype != np.uint8:
+            raise ValueError("gather_tiles: interior of tile %r has the wrong shape or type" % (t,))
+        flat[pos:pos + a.size] = a.reshape(-1)
+        pos += a.size
+    if world == 1:
+        parts = [torch.from_numpy(flat)]
+    else:
+        mine = torch.from_numpy(flat).to(device)
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, parts, dst=dst)
+        if rank != dst:
+            return None
+    out = np.zeros((2 * height, 2 * width, 4), np.uint8)
+    for r, ts in enumerate(per_rank):
+        buf = parts[r].cpu().numpy()
+        pos = 0
+        for t in ts:
+            n = 16 * (t.x1 - t.x0) * (t.y1 - t.y0)
+            out[2 * t.y0:2 * t.y1, 2 * t.x0:2 * t.x1] = buf[pos:pos + n].reshape(2 * (t.y1 - t.y0), 2 * (t.x1 - t.x0), 4)
+            pos += n
+    return out
+
+
 def max_over_ranks(seconds):
     """Slowest rank's time (what a frame-sharded job takes); identity without a process group."""
     import torch

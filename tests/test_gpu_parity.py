@@ -331,3 +331,21 @@ def test_frame_pipe_rgb8_buffers(w, h):
         with pytest.raises(S.SrxError):
             from superresolution_amd._capi import _check
             _check(pipe._L.srx_pipe_set_channels(pipe._h, 4, 4))        # too late: slots were submitted
+
+
+@pytest.mark.gpu
+def test_8k_image_in_eight_halo_tiles_equals_whole_image():
+    """The spatial partition at its full size: a 7680x4320 image cut into 2 x 4 tiles with a 7-pixel
+    halo gives, tile by tile, the bytes of the untiled run (each tile here is what one of eight GPUs
+    would process).  The whole image needs one 8.5 GB activation buffer: the workspace limit is a
+    preference, not a cap."""
+    from superresolution_amd import sharding
+    W, H = 7680, 4320
+    rng = np.random.default_rng(77)
+    small = rng.integers(0, 256, (H // 8, W // 8, 4), dtype=np.uint8)
+    img = np.ascontiguousarray(np.kron(small, np.ones((8, 8, 1), np.uint8)))      # blocky, with real edges
+    img[..., :3] ^= rng.integers(0, 8, (H, W, 3), dtype=np.uint8)                  # plus fine noise
+    with S.SuperResolutionContext(W, H) as ctx:
+        whole = ctx.run(img)
+    tiled = sharding.upscale_tiled(img, 2, 4)
+    assert np.array_equal(tiled, whole)

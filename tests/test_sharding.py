@@ -52,6 +52,16 @@ def _worker(rank, world, port, q):
     for t in tiles:
         mine[10 + plan.index(t)] += 1
     dist.all_reduce(mine)
+    # the optional gather of tile interiors to one rank
+    import numpy as np
+    W, H = 50, 38
+    truth = np.random.default_rng(5).integers(0, 256, (2 * H, 2 * W, 4), dtype=np.uint8)
+    big = sh.tile_plan(W, H, 3, 2)
+    interiors = [np.ascontiguousarray(truth[2 * t.y0:2 * t.y1, 2 * t.x0:2 * t.x1]) for t in sh.tiles_for_rank(big, rank, world)]
+    whole = sh.gather_tiles(interiors, W, H, 3, 2, rank, world, dst=1)
+    assert (whole is None) == (rank != 1)
+    if rank == 1:
+        assert np.array_equal(whole, truth)
     slowest = sh.max_over_ranks(1.0 + rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -76,3 +86,13 @@ def test_two_ranks_gloo():
     for rank, counts, slowest in results:
         assert counts == [1] * 14          # every frame and every tile exactly once across ranks
         assert slowest == 2.0              # the job takes as long as its slowest rank
+
+
+def test_gather_tiles_single_rank():
+    W, H = 21, 17
+    truth = np.random.default_rng(6).integers(0, 256, (2 * H, 2 * W, 4), dtype=np.uint8)
+    plan = sharding.tile_plan(W, H, 2, 3)
+    interiors = [np.ascontiguousarray(truth[2 * t.y0:2 * t.y1, 2 * t.x0:2 * t.x1]) for t in plan]
+    assert np.array_equal(sharding.gather_tiles(interiors, W, H, 2, 3, 0, 1), truth)
+    with pytest.raises(ValueError):
+        sharding.gather_tiles(interiors[:-1], W, H, 2, 3, 0, 1)
