@@ -96,6 +96,24 @@ def pcie_inclusive(S, frames, device):
                     "upload / compute / download on three streams, RGB8 buffers); 6.2 MB in + 24.9 MB out per frame over PCIe"}
 
 
+def single_frame_latency(S, frame, device, reps=50):
+    """The batch-1 configuration: one resident 1080p frame, upscale + synchronize, median of `reps`."""
+    import torch
+    with S.SuperResolutionContext(W, H, batch=1, device=device) as ctx:
+        ctx.upload_rgba8(0, frame)
+        stream = torch.cuda.current_stream().cuda_stream or None
+        for _ in range(5):
+            ctx.upscale(stream)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctx.upscale(stream)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    return round(sorted(times)[len(times) // 2] * 1e3, 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +165,7 @@ def main():
     barrier()
 
     # per-kernel durations, HIP events on the launch stream (one launch covers the frames of
-    # one workspace pass: 1 frame at this size)
+    # one workspace pass: ctx.frames_per_launch, 8 at this size)
     names = ctx.stage_names()
     stage_ms = {}
     if rank == 0:
@@ -166,7 +184,7 @@ def main():
         frames = B * world * args.steps
         fps = frames / elapsed
         value = fps * OUT_MP
-        frames_per_launch = ctx.frames_per_launch      # frames one conv-stage launch covers (1 at 1080p)
+        frames_per_launch = ctx.frames_per_launch      # frames one launch of either fused kernel covers
         # dominant kernel = the conv stage with the longest launch
         dom = max((n for n in stage_ms if n in FLOP_PER_LR_PIXEL), key=lambda n: stage_ms[n])
         dom_s = stage_ms[dom] / 1e3
@@ -213,6 +231,8 @@ def main():
                                  "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
+        if world == 1:
+            out["latency_ms_single_frame"] = single_frame_latency(S, distinct[0], local_rank)
         if world == 1 and not args.no_pcie_leg:
             out["pcie_inclusive"] = pcie_inclusive(S, distinct, local_rank)
         if world == 1 and not args.no_cpu_baseline:
