@@ -349,3 +349,48 @@ def test_8k_image_in_eight_halo_tiles_equals_whole_image():
         whole = ctx.run(img)
     tiled = sharding.upscale_tiled(img, 2, 4)
     assert np.array_equal(tiled, whole)
+
+
+@pytest.mark.gpu
+def test_fused_path_random_sizes_against_layerwise_path():
+    """Thirty seeded random shapes (1..150 per side, 1..3 frames): the two fused kernels against the
+    layer-wise kernels, which differ only in the order of conv6's fp32 sums."""
+    rng = np.random.default_rng(20240611)
+    for _ in range(30):
+        w, h, batch = int(rng.integers(1, 151)), int(rng.integers(1, 151)), int(rng.integers(1, 4))
+        frames = [synthetic_rgba(w, h, int(rng.integers(1 << 30))) for _ in range(batch)]
+        outs = []
+        for flags in (S.FLAG_KEEP_TENSORS, 0):
+            with S.SuperResolutionContext(w, h, batch=batch, flags=flags) as ctx:
+                for i, f in enumerate(frames):
+                    ctx.upload_rgba8(i, f)
+                ctx.upscale()
+                ctx.sync()
+                outs.append([ctx.tensor_to_image(i) for i in range(batch)])
+        for a, b in zip(*outs):
+            d = np.abs(a.astype(int) - b.astype(int))
+            assert d.max() <= 1, (w, h, batch)
+            assert (d == 0).mean() >= 0.99 or d.size < 400, (w, h, batch)
+
+
+@pytest.mark.gpu
+def test_small_workspace_runs_the_batch_in_several_passes(monkeypatch):
+    """SRX_WORKSPACE_MB below the batch's need: the frames go through the two kernels in passes
+    (here 2 + 2 + 1), with the same bytes out as in one pass."""
+    w, h, batch = 180, 90, 5
+    frames = [synthetic_rgba(w, h, 900 + i) for i in range(batch)]
+
+    def run():
+        with S.SuperResolutionContext(w, h, batch=batch) as ctx:
+            for i, f in enumerate(frames):
+                ctx.upload_rgba8(i, f)
+            ctx.upscale()
+            ctx.sync()
+            return ctx.frames_per_launch, [ctx.tensor_to_image(i) for i in range(batch)]
+
+    n_all, want = run()
+    monkeypatch.setenv("SRX_WORKSPACE_MB", "12")     # one frame of the workspace tensor is 5.6 MB
+    n_few, got = run()
+    assert n_all == batch and n_few == 2
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
