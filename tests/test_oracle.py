@@ -217,3 +217,24 @@ def test_reference_stb_decodes_like_pil(oracle):
         buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
         R.ref_free(p)
         assert np.array_equal(buf, load_png_rgba(os.path.join(ASSETS, name)))
+
+
+def _psnr(a, b):
+    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    return 10 * np.log10(255.0 ** 2 / (d ** 2).mean())
+
+
+def test_bundled_image_pair_pins_the_meaning_of_the_graph(oracle, oracle_weights):
+    """A known answer the reference itself ships: Sashimi128.png is the 2x2 box average of
+    Sashimi.png (the two differ by at most 1.25 grey levels after averaging), so the network's
+    output for Sashimi128 must restore Sashimi better than plain interpolation does.  A wrong layer
+    order, channel order, weight layout or batch-norm fold does not gain 4 dB over nearest-neighbour:
+    this pins the restatement's semantics on data independent of it."""
+    lo, hi = CASES["sashimi128"](), CASES["sashimi"]()
+    assert hi.shape == (256, 256, 4) and lo.shape == (128, 128, 4)
+    box = hi[..., :3].astype(np.float64).reshape(128, 2, 128, 2, 3).mean((1, 3))
+    assert np.abs(box - lo[..., :3]).max() <= 1.25
+    out = oracle.Model(oracle_weights).run(lo)
+    nearest = np.repeat(np.repeat(lo, 2, 0), 2, 1)
+    gain = _psnr(out, hi) - _psnr(nearest, hi)
+    assert _psnr(out, hi) > 33.0 and gain > 3.5, (_psnr(out, hi), gain)
