@@ -4,11 +4,14 @@
 // (fp16 or fp32 storage, fp32 arithmetic) and layout (NCHW or NHWC), plus the two shader passes
 // (CSImageToTensor.hlsl, PSTensorToImage.hlsl) for those data types and layouts.
 //
-// These are direct, LDS-tiled VALU kernels: they serve the fp32 tensor mode, the NHWC switch and
-// other small networks.  The fp16 fast path of the sample network does not use them (it runs on the
-// fused MFMA kernels).
+// The convolution of fp16 tensors is an LDS-tiled implicit GEMM on the matrix cores
+// (ConvMfmaKernel); fp32 tensors use a direct, LDS-tiled VALU kernel.  They serve the fp32 tensor
+// mode, the NHWC switch and other small networks.  The fp16 fast path of the sample network does not
+// use them (it runs on the fused MFMA kernels).
 #include "srx_device.h"
 #include "srx_weights.h"
+
+#include <cstdlib>
 
 namespace srx {
 
@@ -111,6 +114,164 @@ __global__ __launch_bounds__(256) void ConvDirectKernel(const ConvArgs a)
         if (a.bias) v += loadF(static_cast<const T*>(a.bias), size_t(o0 + o));
         if (a.relu) v = fmaxf(v, 0.0f);
         storeF(out, at<NHWC>(n, o0 + o, y, x, a.O, a.H, a.W), v);
+    }
+}
+
+// The same convolution for fp16 tensors on the matrix cores: implicit GEMM with
+// v_mfma_f32_32x32x16_f16, A = filter (32 output channels x 16 input channels of one tap),
+// B = activations (16 input channels x 32 consecutive pixels of a row).  A workgroup (4 waves) makes
+// 32 x 8 pixels x 32 output channels; wave w makes rows 2w and 2w+1.  Per pass of 16 input channels
+// the input tile with its halo and the filter slice are staged in LDS as [pixel][16 channels] and
+// [tap][output][16 channels], 48 bytes apart (an odd number of 16-byte slots: conflict-free
+// ds_read_b128 fragments).  fp32 accumulation; bias, ReLU and the rounding to fp16 as in the direct kernel.
+constexpr int kMO = 32;               // output channels per workgroup
+constexpr int kMC = 16;               // input channels per pass (one MFMA K-step)
+constexpr int kSlot = 48;             // bytes per pixel / per filter row in LDS
+
+__host__ __device__ inline int convMfmaInBytes(int kh, int kw) { return (kTH + kh - 1) * (kTW + kw - 1) * kSlot; }
+__host__ __device__ inline int convMfmaLdsBytes(int kh, int kw) { return convMfmaInBytes(kh, kw) + kh * kw * kMO * kSlot; }
+
+template <bool NHWC>
+__global__ __launch_bounds__(256) void ConvMfmaKernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const f16* in = static_cast<const f16*>(a.in);
+    const f16* filter = static_cast<const f16*>(a.filter);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, n = blockIdx.z, o0 = blockIdx.y * kMO;
+    const int x0 = (tile % a.tilesX) * kTW, y0 = (tile / a.tilesX) * kTH;
+    const int inH = kTH + a.kh - 1, inW = kTW + a.kw - 1, taps = a.kh * a.kw;
+    char* sIn = smem;
+    char* sW = smem + convMfmaInBytes(a.kh, a.kw);
+    const float invInW = 1.0f / float(inW), invTaps = 1.0f / float(taps);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+
+    for (int c0 = 0; c0 < a.C; c0 += kMC)
+    {
+        const int cn = min(kMC, a.C - c0);
+        __syncthreads();
+        // Staging.  Channels beyond the tensor's and pixels outside the image are zeros.  Small
+        // quotients are taken with a float reciprocal (exact for these ranges, all below 1024).
+        if (NHWC && (a.C & 7) == 0)
+        {
+            // 8 channels = 16 contiguous, aligned bytes per pixel and per filter tap
+            for (int i = tid; i < inH * inW * 2; i += 256)
+            {
+                const int r = i >> 1, hh = i & 1;
+                const int yy = int((r + 0.5f) * invInW), xx = r - yy * inW;
+                const int y = y0 + yy - a.padTop, x = x0 + xx - a.padLeft;
+                uint4 v = uint4{0, 0, 0, 0};
+                if (c0 + 8 * hh < a.C && y >= 0 && y < a.H && x >= 0 && x < a.W)
+                    v = *reinterpret_cast<const uint4*>(in + at<true>(n, c0 + 8 * hh, y, x, a.C, a.H, a.W));
+                *reinterpret_cast<uint4*>(sIn + r * kSlot + hh * 16) = v;
+            }
+            for (int i = tid; i < kMO * taps * 2; i += 256)
+            {
+                const int r = i >> 1, hh = i & 1;
+                const int o = int((r + 0.5f) * invTaps), t = r - o * taps;
+                uint4 v = uint4{0, 0, 0, 0};
+                if (o0 + o < a.O && c0 + 8 * hh < a.C)
+                    v = *reinterpret_cast<const uint4*>(filter + (size_t(o0 + o) * taps + t) * a.C + c0 + 8 * hh);
+                *reinterpret_cast<uint4*>(sW + (t * kMO + o) * kSlot + hh * 16) = v;
+            }
+        }
+        else if (NHWC)
+        {
+            for (int i = tid; i < kMC * inH * inW; i += 256)
+            {
+                const int c = i & (kMC - 1), r = i >> 4;
+                const int yy = int((r + 0.5f) * invInW), xx = r - yy * inW;
+                const int y = y0 + yy - a.padTop, x = x0 + xx - a.padLeft;
+                f16 v = f16(0.0f);
+                if (c < cn && y >= 0 && y < a.H && x >= 0 && x < a.W) v = in[at<true>(n, c0 + c, y, x, a.C, a.H, a.W)];
+                *reinterpret_cast<f16*>(sIn + r * kSlot + c * 2) = v;
+            }
+            for (int i = tid; i < kMO * kMC * taps; i += 256)
+            {
+                const int c = i & (kMC - 1), r = i >> 4;
+                const int o = int((r + 0.5f) * invTaps), t = r - o * taps;
+                f16 v = f16(0.0f);
+                if (o0 + o < a.O && c < cn) v = filter[(size_t(o0 + o) * taps + t) * a.C + c0 + c];
+                *reinterpret_cast<f16*>(sW + (t * kMO + o) * kSlot + c * 2) = v;
+            }
+        }
+        else
+        {
+            // NCHW / OIHW: the 8 channels of a fragment half lie in 8 planes; a thread gathers them
+            // (lanes run along x, so each of the 8 loads is coalesced) and writes 16 bytes at once
+            for (int i = tid; i < inH * inW * 2; i += 256)
+            {
+                const int r = i % (inH * inW), hh = i / (inH * inW);
+                const int yy = int((r + 0.5f) * invInW), xx = r - yy * inW;
+                const int y = y0 + yy - a.padTop, x = x0 + xx - a.padLeft;
+                f16x8 v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = f16(0.0f);
+                if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+                {
+                    const f16* src = in + at<false>(n, c0 + 8 * hh, y, x, a.C, a.H, a.W);
+                    const size_t plane = size_t(a.H) * a.W;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (8 * hh + k < cn) v[k] = src[k * plane];
+                }
+                *reinterpret_cast<f16x8*>(sIn + r * kSlot + hh * 16) = v;
+            }
+            for (int i = tid; i < kMO * taps * 2; i += 256)
+            {
+                const int r = i % (kMO * taps), hh = i / (kMO * taps);
+                const int o = int((r + 0.5f) * invTaps), t = r - o * taps;
+                f16x8 v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = f16(0.0f);
+                if (o0 + o < a.O)
+                {
+                    const f16* src = filter + (size_t(o0 + o) * a.C + c0 + 8 * hh) * taps + t;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (8 * hh + k < cn) v[k] = src[k * taps];
+                }
+                *reinterpret_cast<f16x8*>(sW + (t * kMO + o) * kSlot + hh * 16) = v;
+            }
+        }
+        __syncthreads();
+        const char* aBase = sW + px * kSlot + h * 16;
+        const char* bBase = sIn + (2 * wave * inW + px) * kSlot + h * 16;
+        for (int ki = 0; ki < a.kh; ++ki)
+            for (int kj = 0; kj < a.kw; ++kj)
+            {
+                const f16x8 w = *reinterpret_cast<const f16x8*>(aBase + (ki * a.kw + kj) * kMO * kSlot);
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(bBase + (ki * inW + kj) * kSlot);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(bBase + ((ki + 1) * inW + kj) * kSlot);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b1, acc1, 0, 0, 0);
+            }
+    }
+
+    // D: lane (px, h) holds, for its pixel, output channels (r & 3) + 8 * (r >> 2) + 4 * h
+    const int x = x0 + px;
+    if (x >= a.W) return;
+    f16* out = static_cast<f16*>(a.out);
+    const f16* bias = static_cast<const f16*>(a.bias);
+#pragma unroll
+    for (int row = 0; row < 2; ++row)
+    {
+        const int y = y0 + 2 * wave + row;
+        if (y >= a.H) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (o >= a.O) continue;
+            float v = row ? acc1[r] : acc0[r];
+            if (bias) v += (float)bias[o];
+            if (a.relu) v = fmaxf(v, 0.0f);
+            out[at<NHWC>(n, o, y, x, a.O, a.H, a.W)] = (f16)v;
+        }
     }
 }
 
@@ -229,6 +390,27 @@ hipError_t DispatchOperator(const ML::Operator& op, const void* input, const voi
         a.tilesY = (a.H + kTH - 1) / kTH;
         if (a.N > 65535 || (a.O + kOT - 1) / kOT > 65535) return hipErrorInvalidValue;
         const dim3 grid(a.tilesX * a.tilesY, (a.O + kOT - 1) / kOT, a.N), block(256);
+        if (op.dataType == ML::TensorDataType::FLOAT16 && !getenv("SRX_GENERIC_VALU"))
+        {
+            // fp16 tensors run on the matrix cores (SRX_GENERIC_VALU keeps the direct kernel, for comparison)
+            const int lds = convMfmaLdsBytes(a.kh, a.kw);
+            int device = 0;
+            if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
+            static bool attr[64] = {};
+            if (!attr[device])
+            {
+                const int most = convMfmaLdsBytes(kKMax, kKMax);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ConvMfmaKernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ConvMfmaKernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+                if (e != hipSuccess) return e;
+                attr[device] = true;
+            }
+            const dim3 mgrid(a.tilesX * a.tilesY, (a.O + kMO - 1) / kMO, a.N);
+            if (nhwc) hipLaunchKernelGGL((ConvMfmaKernel<true>), mgrid, block, lds, s, a);
+            else hipLaunchKernelGGL((ConvMfmaKernel<false>), mgrid, block, lds, s, a);
+            return hipGetLastError();
+        }
         return byType(op.dataType,
                       [&] { if (nhwc) hipLaunchKernelGGL((ConvDirectKernel<f16, true>), grid, block, 0, s, a);
                             else hipLaunchKernelGGL((ConvDirectKernel<f16, false>), grid, block, 0, s, a); },
