@@ -95,7 +95,8 @@ def conv_ref(x, w, b, relu):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("shape", [(2, 5, 19, 45, 3, 4, 7, True), (1, 3, 9, 33, 17, 1, 1, False), (1, 20, 8, 8, 33, 7, 2, True)])
+@pytest.mark.parametrize("shape", [(2, 5, 19, 45, 3, 4, 7, True), (1, 3, 9, 33, 17, 1, 1, False), (1, 20, 8, 8, 33, 7, 2, True),
+                                   (1, 24, 12, 40, 40, 3, 3, True), (2, 64, 9, 70, 64, 5, 5, True), (1, 8, 17, 31, 1, 2, 2, False)])
 def test_conv_layer_any_shape(dtype, layout, shape):
     n, c, H, W, o, kh, kw, bias = shape
     rng = np.random.default_rng(n * 100 + c)
