@@ -262,6 +262,27 @@ __global__ __launch_bounds__(256) void ConvMfmaKernel(const ConvArgs a)
     {
         const int y = y0 + 2 * wave + row;
         if (y >= a.H) break;
+        if (NHWC && (a.O & 3) == 0)
+        {
+            // four consecutive output channels of a pixel are 8 contiguous, aligned bytes
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                const int o = o0 + 8 * g + 4 * h;
+                if (o >= a.O) continue;
+                f16x4 v4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    float v = row ? acc1[4 * g + k] : acc0[4 * g + k];
+                    if (bias) v += (float)bias[o + k];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    v4[k] = (f16)v;
+                }
+                *reinterpret_cast<f16x4*>(out + at<true>(n, o, y, x, a.O, a.H, a.W)) = v4;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
         {
