@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-reps", type=int, default=20)
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the host-to-host (PCIe inclusive) measurement")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the single-frame latency measurement")
     args = ap.parse_args()
 
     import torch
@@ -231,7 +232,7 @@ def main():
                                  "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
-        if world == 1:
+        if world == 1 and not args.no_latency_leg:
             out["latency_ms_single_frame"] = single_frame_latency(S, distinct[0], local_rank)
         if world == 1 and not args.no_pcie_leg:
             out["pcie_inclusive"] = pcie_inclusive(S, distinct, local_rank)

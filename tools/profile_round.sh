@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- \
-    python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-leg --stage-reps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log" || exit 1
+    python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-leg --no-latency-leg --stage-reps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log" || exit 1
 for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
     timeout -s KILL 120 rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o pmc --output-format csv -- \
         python3 "$R/tools/time_stages.py" --batch 8 --reps 3 > "$OUT/pmc_$C.log" 2>&1 || exit 1
