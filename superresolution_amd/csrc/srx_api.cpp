@@ -931,7 +931,9 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
         return fail(SRX_ERR_INVALID, "srx_pipe_create: the ctx's batch must hold at least two slots of frames_per_slot frames");
     if (c->keep() || c->generic()) return fail(SRX_ERR_STATE, "srx_pipe_create: not available with SRX_FLAG_KEEP_TENSORS or the generic-layer graph");
     SRX_HIP(hipSetDevice(c->device));
-    srx_pipe* p = new srx_pipe;
+    struct Destroy { void operator()(srx_pipe* x) const { srx_pipe_destroy(x); } };
+    std::unique_ptr<srx_pipe, Destroy> owner(new srx_pipe);    // released on success only
+    srx_pipe* p = owner.get();
     p->ctx = c;
     p->perSlot = framesPerSlot;
     p->slots = c->batch / framesPerSlot;
@@ -947,7 +949,6 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
     p->submitted.assign(p->slots, false);
     const auto bail = [&](hipError_t e, const char* what) {
         const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
-        srx_pipe_destroy(p);
         return fail(e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_HIP, msg);
     };
     hipError_t e;
@@ -962,7 +963,7 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
         for (hipEvent_t* ev : {&p->evUp[s], &p->evComp[s], &p->evDown[s]})
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreateWithFlags");
     }
-    *out = p;
+    *out = owner.release();
     return SRX_OK;
 }
 SRX_CATCH
@@ -977,18 +978,25 @@ srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outC
         if (p->submitted[s]) return fail(SRX_ERR_STATE, "srx_pipe_set_channels: call it before the first srx_pipe_submit");
     srx_ctx* c = p->ctx;
     SRX_HIP(hipSetDevice(c->device));
+    // RGB8 staging buffers, one per slot; a failed allocation leaves none behind, so a later call starts over
+    const auto allocPerSlot = [&](std::vector<uint8_t*>& v, size_t bytes) -> hipError_t {
+        v.assign(p->slots, nullptr);
+        for (uint32_t s = 0; s < p->slots; ++s)
+        {
+            const hipError_t e = hipMalloc(reinterpret_cast<void**>(&v[s]), bytes);
+            if (e != hipSuccess)
+            {
+                for (uint8_t* d : v) if (d) (void)hipFree(d);
+                v.clear();
+                return e;
+            }
+        }
+        return hipSuccess;
+    };
     if (inChannels == 3 && p->devRgbIn.empty())
-    {
-        p->devRgbIn.assign(p->slots, nullptr);
-        for (uint32_t s = 0; s < p->slots; ++s)
-            SRX_HIP(hipMalloc(reinterpret_cast<void**>(&p->devRgbIn[s]), size_t(c->width) * c->height * 3 * p->perSlot));
-    }
+        SRX_HIP(allocPerSlot(p->devRgbIn, size_t(c->width) * c->height * 3 * p->perSlot));
     if (outChannels == 3 && p->devRgbOut.empty())
-    {
-        p->devRgbOut.assign(p->slots, nullptr);
-        for (uint32_t s = 0; s < p->slots; ++s)
-            SRX_HIP(hipMalloc(reinterpret_cast<void**>(&p->devRgbOut[s]), size_t(c->width) * c->height * 12 * p->perSlot));
-    }
+        SRX_HIP(allocPerSlot(p->devRgbOut, size_t(c->width) * c->height * 12 * p->perSlot));
     p->inChannels = inChannels;
     p->outChannels = outChannels;
     p->inPitch = size_t(c->width) * inChannels;
