@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time every stage of one 1920x1080 upscale with HIP events (development helper).
+"""Time every stage of an upscale with HIP events (development helper).
 
   python tools/time_stages.py [--reps 30] [--w 1920 --h 1080] [--batch 1]
 """
@@ -39,7 +39,7 @@ def main():
             ctx.launch_stage(i, stream)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / a.reps / (a.batch if i == 0 else fpl)
+        ms = e0.elapsed_time(e1) / a.reps / fpl          # a launch covers the frames of one pass
         total += ms
         print(f"{name:32s} {ms:8.4f} ms/frame")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
