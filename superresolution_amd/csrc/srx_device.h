@@ -91,13 +91,18 @@ void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream
 inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
 
 // Workgroups per launch: two per CU (or one when `perCU` is 1), a multiple of 8 so that the
-// XCD-aware walk applies, never more than there are work items.
+// XCD-aware walk applies.  With fewer work items than that, one workgroup per item, rounded UP to
+// a multiple of 8: the few workgroups without an item leave at once (TileWalk gives them an empty
+// range), whereas rounding down would send the last items into a second round.
 inline int gridFor(int numItems, int numCUs, int perCU = 2)
 {
-    int g = numCUs * perCU;
-    if (numItems < g) g = numItems;
-    if (g >= 8) g &= ~7;
-    return g < 1 ? 1 : g;
+    int most = numCUs * perCU;
+    if (most >= 8) most &= ~7;
+    if (most < 1) most = 1;
+    if (numItems >= most) return most;
+    if (numItems <= 8) return numItems < 1 ? 1 : numItems;
+    const int up = (numItems + 7) & ~7;
+    return up <= most ? up : most;
 }
 
 }  // namespace dev
