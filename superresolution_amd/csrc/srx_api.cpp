@@ -224,13 +224,18 @@ srx_status allocTensors(srx_ctx* c)
     uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(maxChunk, (size_t(256) << 20) / perFrame)));
     if (!c->keep())
     {
+        // cost of one pass of n frames, and of the whole batch in passes of n (the last pass takes the rest)
+        const auto passCost = [&](uint32_t n) {
+            const srx::StripPlan lr = srx::PlanLrFused(int(c->width), int(c->height), int(n), c->numCUs);
+            const srx::StripPlan hr = srx::PlanHrFused(2 * int(c->width), 2 * int(c->height), int(n), c->numCUs);
+            return 3.2 * lr.steps * lr.rounds + 1.0 * hr.steps * hr.rounds;
+        };
         double best = 0.0;
         const uint32_t first = chunk, last = std::min<uint32_t>(maxChunk, chunk + 64);
         for (uint32_t n = first; n <= last; ++n)
         {
-            const srx::StripPlan lr = srx::PlanLrFused(int(c->width), int(c->height), int(n), c->numCUs);
-            const srx::StripPlan hr = srx::PlanHrFused(2 * int(c->width), 2 * int(c->height), int(n), c->numCUs);
-            const double cost = (3.2 * lr.steps * lr.rounds + 1.0 * hr.steps * hr.rounds) / n;
+            const uint32_t rest = c->batch % n;
+            const double cost = (c->batch / n) * passCost(n) + (rest ? passCost(rest) : 0.0);
             if (n == first || cost < best * 0.98)
             {
                 best = cost;
