@@ -60,10 +60,23 @@ def cpu_baseline():
     t0 = time.perf_counter()
     model.run(crop)
     dt = time.perf_counter() - t0
-    return {"value": round(4 * cw * ch / 1e6 / dt, 4), "unit": "output megapixels/s", "cores": threads,
-            "kind": "port",
-            "sample": f"one whole synthetic {cw}x{ch} frame through oracle/sr_oracle.c "
-                      f"(reference graph, direct conv_up1), OpenMP {threads} threads, {dt:.2f} s"}
+    out = {"value": round(4 * cw * ch / 1e6 / dt, 4), "unit": "output megapixels/s", "cores": threads,
+           "kind": "port",
+           "sample": f"one whole synthetic {cw}x{ch} frame through oracle/sr_oracle.c "
+                     f"(reference graph, direct conv_up1), OpenMP {threads} threads, {dt:.2f} s"}
+    # the reference's own CPU-sized case on one thread: the bundled 128x128 image
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        small = sro.load_rgba(os.path.join(os.path.dirname(S.default_weights_path()), "Sashimi128.png"))
+        t0 = time.perf_counter()
+        model.run(small)
+        dt1 = time.perf_counter() - t0
+        out["single_thread"] = {"value": round(4 * 128 * 128 / 1e6 / dt1, 4), "unit": "output megapixels/s",
+                                "sample": f"Sashimi128.png (128x128), one thread, {dt1:.2f} s"}
+    except OSError:
+        pass
+    return out
 
 
 def pcie_inclusive(S, frames, device):
