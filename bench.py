@@ -245,6 +245,9 @@ def main():
                                  "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
+        info = ctx.device_info()
+        out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "max_clock_mhz": info["clock_khz"] // 1000,
+                         "peak_note": "2.5 PFLOP/s = 256 CUs x 4096 fp16 FLOP/clk x 2.4 GHz"}
         if world == 1 and not args.no_latency_leg:
             out["latency_ms_single_frame"] = single_frame_latency(S, distinct[0], local_rank)
         if world == 1 and not args.no_pcie_leg:

@@ -183,6 +183,12 @@ srx_status  srx_launch_stage(srx_ctx* ctx, int32_t i, void* stream);
 /* Frames one srx_launch_stage() of a convolution stage covers (the activation
  * workspace holds this many frames; srx_process walks the batch in such passes). */
 uint32_t    srx_frames_per_launch(const srx_ctx* ctx);
+/* What the ctx's device is: compute units, peak engine clock in kHz and the architecture name
+ * (the counterpart of the DXGI_ADAPTER_DESC1 the reference reads when it picks its adapter,
+ * SuperResolutionX.cpp:76-116).  Any
+ * output pointer may be NULL; arch receives at most arch_cap bytes including the terminator. */
+srx_status  srx_device_info(const srx_ctx* ctx, int32_t* compute_units, int32_t* clock_khz,
+                            char* arch, size_t arch_cap);
 
 /*
  * Frame pipe: the counterpart of the reference's frames in flight

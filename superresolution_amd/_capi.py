@@ -19,7 +19,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_upload_rgb8", "srx_input_device_ptr", "srx_output_device_ptr", "srx_image_to_tensor",
            "srx_process", "srx_tensor_to_image", "srx_upscale", "srx_sync", "srx_read_tensor",
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
-           "srx_launch_stage", "srx_frames_per_launch", "srx_last_error", "srx_upscale_frames",
+           "srx_launch_stage", "srx_frames_per_launch", "srx_device_info", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
            "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan"]
 
@@ -87,6 +87,7 @@ def lib():
     L.srx_launch_stage.argtypes = [vp, i32, vp]
     L.srx_last_error.restype = C.c_char_p
     L.srx_frames_per_launch.argtypes = [vp]
+    L.srx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
     L.srx_upscale_frames.argtypes = [vp, u32, u32, vp]
     L.srx_pipe_create.argtypes = [vp, u32, C.POINTER(vp)]
     L.srx_pipe_destroy.argtypes = [vp]
@@ -203,6 +204,13 @@ class SuperResolutionContext:
     @property
     def frames_per_launch(self):
         return self._L.srx_frames_per_launch(self._h)
+
+    def device_info(self):
+        """{'compute_units', 'clock_khz', 'arch'} of the ctx's GPU."""
+        cus, khz = C.c_int32(0), C.c_int32(0)
+        arch = C.create_string_buffer(64)
+        _check(self._L.srx_device_info(self._h, C.byref(cus), C.byref(khz), arch, 64))
+        return {"compute_units": cus.value, "clock_khz": khz.value, "arch": arch.value.decode()}
 
     def launch_stage(self, i, stream=None):
         _check(self._L.srx_launch_stage(self._h, i, stream))

@@ -800,6 +800,22 @@ const char* srx_stage_name(const srx_ctx* c, int32_t i)
 
 uint32_t srx_frames_per_launch(const srx_ctx* c) { return validCtx(c) ? std::min(c->chunk, c->batch) : 0; }
 
+srx_status srx_device_info(const srx_ctx* c, int32_t* computeUnits, int32_t* clockKHz, char* arch, size_t archCap) try
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    hipDeviceProp_t prop;
+    SRX_HIP(hipGetDeviceProperties(&prop, c->device));
+    if (computeUnits) *computeUnits = prop.multiProcessorCount;
+    if (clockKHz) *clockKHz = prop.clockRate;
+    if (arch && archCap)
+    {
+        std::strncpy(arch, prop.gcnArchName, archCap - 1);
+        arch[archCap - 1] = 0;
+    }
+    return SRX_OK;
+}
+SRX_CATCH
+
 srx_status srx_launch_stage(srx_ctx* c, int32_t i, void* stream) try
 {
     if (!validCtx(c) || i < 0 || i >= int32_t(c->stages.size())) return fail(SRX_ERR_INVALID, "srx_launch_stage: bad stage");
