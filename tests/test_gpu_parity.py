@@ -431,3 +431,10 @@ def test_full_hd_runs_are_deterministic():
                 digests.append([hashlib.sha256(ctx.tensor_to_image(i).tobytes()).hexdigest() for i in range(8)])
     assert all(d == digests[0] for d in digests[1:])
     assert len(set(digests[0])) == 8
+
+
+@pytest.mark.gpu
+def test_device_info():
+    with S.SuperResolutionContext(16, 16) as ctx:
+        info = ctx.device_info()
+    assert info["arch"].startswith("gfx950") and info["compute_units"] >= 8 and info["clock_khz"] > 100000
