@@ -228,7 +228,7 @@ srx_status allocTensors(srx_ctx* c)
         const auto passCost = [&](uint32_t n) {
             const srx::StripPlan lr = srx::PlanLrFused(int(c->width), int(c->height), int(n), c->numCUs);
             const srx::StripPlan hr = srx::PlanHrFused(2 * int(c->width), 2 * int(c->height), int(n), c->numCUs);
-            return 3.2 * lr.steps * lr.rounds + 1.0 * hr.steps * hr.rounds;
+            return 3.2 * double(lr.cost) + 1.0 * double(hr.cost);
         };
         double best = 0.0;
         const uint32_t first = chunk, last = std::min<uint32_t>(maxChunk, chunk + 64);

@@ -357,18 +357,29 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     StripPlan pl;
     if (width2 <= 0 || height2 <= 0 || batch <= 0 || numCUs <= 0) return pl;
     pl.strips = (width2 + kHrStrip - 1) / kHrStrip;
-    // split the rows so that there are about two work items per CU (two workgroups share a CU); every
-    // segment re-computes about 12 warm-up rows, so keep segments at least 32 rows tall; segments
-    // start at multiples of four rows (conv6 stores blocks of four)
-    int segs = (2 * numCUs + pl.strips * batch - 1) / (pl.strips * batch);
-    const int maxSegs = height2 / 32 > 1 ? height2 / 32 : 1;
-    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
-    pl.segRows = ((height2 + segs - 1) / segs + 3) & ~3;
-    pl.segs = (height2 + pl.segRows - 1) / pl.segRows;
-    pl.items = pl.strips * pl.segs * batch;
-    pl.steps = pl.segRows + 16;
-    const int slots = gridFor(pl.items, numCUs);
-    pl.rounds = (pl.items + slots - 1) / slots;
+    // Rows are cut into segments where that fills the CUs better (two workgroups share a CU): every
+    // segment re-computes 16 warm-up rows, so segments are at least 32 rows tall, and they start at
+    // multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
+    const int maxSegs = height2 / 32 > 1 ? (height2 / 32 < 64 ? height2 / 32 : 64) : 1;
+    long bestCost = 0;
+    for (int segs = 1; segs <= maxSegs; ++segs)
+    {
+        StripPlan c = pl;
+        c.segRows = ((height2 + segs - 1) / segs + 3) & ~3;
+        c.segs = (height2 + c.segRows - 1) / c.segRows;
+        c.items = c.strips * c.segs * batch;
+        c.steps = c.segRows + 16;
+        const int slots = gridFor(c.items, numCUs);
+        c.rounds = (c.items + slots - 1) / slots;
+        // a workgroup that has its CU to itself takes about 0.72 of the time of one of a pair
+        const int last = c.items - (c.rounds - 1) * slots;
+        c.cost = (100L * (c.rounds - 1) + (2 * last <= slots ? 72 : 100)) * c.steps;
+        if (segs == 1 || c.cost < bestCost)
+        {
+            bestCost = c.cost;
+            pl = c;
+        }
+    }
     return pl;
 }
 

@@ -89,6 +89,7 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 struct StripPlan
 {
     int strips = 0, segs = 0, segRows = 0, items = 0, steps = 0, rounds = 0;
+    long cost = 0;      // estimated duration in row steps x 100 (what the plan minimises)
 };
 StripPlan PlanLrFused(int width, int height, int batch, int numCUs);
 StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);

@@ -573,16 +573,26 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
     StripPlan pl;
     if (width <= 0 || height <= 0 || batch <= 0 || numCUs <= 0) return pl;
     pl.strips = (width + kLrStrip - 1) / kLrStrip;
-    // one work item per CU where the image allows it; a segment re-computes 12 warm-up rows
-    int segs = (numCUs + pl.strips * batch / 2) / (pl.strips * batch);
-    const int maxSegs = height / 32 > 1 ? height / 32 : 1;
-    segs = segs < 1 ? 1 : (segs > maxSegs ? maxSegs : segs);
-    pl.segRows = (height + segs - 1) / segs;
-    pl.segs = (height + pl.segRows - 1) / pl.segRows;
-    pl.items = pl.strips * pl.segs * batch;
-    pl.steps = pl.segRows + 12;
-    const int slots = gridFor(pl.items, numCUs, 1);
-    pl.rounds = (pl.items + slots - 1) / slots;
+    // Rows are cut into segments where that fills the CUs better: every segment re-computes 12 warm-up
+    // rows, and what counts is rounds x steps (one workgroup per CU; segments at least 32 rows tall).
+    const int maxSegs = height / 32 > 1 ? (height / 32 < 64 ? height / 32 : 64) : 1;
+    long bestCost = 0;
+    for (int segs = 1; segs <= maxSegs; ++segs)
+    {
+        StripPlan c = pl;
+        c.segRows = (height + segs - 1) / segs;
+        c.segs = (height + c.segRows - 1) / c.segRows;
+        c.items = c.strips * c.segs * batch;
+        c.steps = c.segRows + 12;
+        const int slots = gridFor(c.items, numCUs, 1);
+        c.rounds = (c.items + slots - 1) / slots;
+        c.cost = 100L * c.rounds * c.steps;
+        if (segs == 1 || c.cost < bestCost)
+        {
+            bestCost = c.cost;
+            pl = c;
+        }
+    }
     return pl;
 }
 
