@@ -1,8 +1,10 @@
 // Development micro-benchmark: the same convolution-like MFMA work (resident filter fragments in
 // VGPRs, one 1-KiB activation fragment read from LDS per 32 cycles of MFMA) issued as
 // v_mfma_f32_32x32x16_f16 or as v_mfma_f32_16x16x32_f16, two waves per SIMD, random data.
-// Prints wall time and in-kernel clock for both, to decide which shape the kernels should use
-// on a power-limited chip.
+// Prints wall time, in-kernel clock and cycles for both, to decide which shape the kernels should
+// use on a power-limited chip; then the 32x32x16 loop with both operands in registers, and both
+// loops with 1..6 independent VALU instructions per MFMA (evenly spread or in bursts), to see what
+// epilogue work beside the MFMAs costs.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_shape_bench tools/mfma_shape_bench.hip && ./mfma_shape_bench
 #include <hip/hip_runtime.h>
 
@@ -127,34 +129,6 @@ __global__ __launch_bounds__(256, 2) void bench(const f16x8* wsrc, const f16* ac
 #pragma unroll
         for (int a = 0; a < 4; ++a) result += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
         result += d[0] + d[1] + d[2] + d[3];
-    }
-    else if constexpr (SHAPE == 2)
-    {
-        // one activation fragment feeds three MFMAs (three output rows in flight): a third of the LDS reads
-        const int px = lane & 31, h = lane >> 5;
-        const int base = px * 144 + h * 16;
-        f32x16 acc[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-        for (int it = 0; it < kIters; ++it)
-        {
-            const int off = base + (it & 7) * 4608;
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-            {
-                const f16x8 b = *reinterpret_cast<const f16x8*>(smem + off + (k / 4) * 144 + (k % 4) * 32);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[3 * k + a], b, acc[a], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[it % 3][r] *= 0.001f;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) result += acc[a][r];
     }
     else if constexpr (SHAPE == 3)
     {
