@@ -238,6 +238,15 @@ def test_full_hd_pass_of_eight_frames_matches_single_frames():
         ctx.sync()
         for i in (0, 1, 6, 7):
             assert np.array_equal(ctx.tensor_to_image(i), singles[i % 2])
+    # a batch that is not a multiple of the pass: 8 frames, then 2 that are cut into segments
+    with S.SuperResolutionContext(W, H, batch=10) as ctx:
+        assert ctx.frames_per_launch == 8
+        for i in range(10):
+            ctx.upload_rgba8(i, frames[i % 2])
+        ctx.upscale()
+        ctx.sync()
+        for i in (0, 7, 8, 9):
+            assert np.array_equal(ctx.tensor_to_image(i), singles[i % 2])
 
 
 def test_frame_pipe_matches_plain_upscale():
