@@ -1,0 +1,18 @@
+// BMP, TGA and binary PNM decoding (see ImageFormats.cpp); used by ImageIO for files that are not PNG.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace srx {
+namespace formats {
+
+// Size and channel count (1, 3 or 4) of a BMP / PNM / TGA file image held in memory.
+bool Info(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err);
+// The decoded pixels, `channels` interleaved bytes per pixel, rows top to bottom.
+bool Decode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
+            std::string& err);
+
+}  // namespace formats
+}  // namespace srx

@@ -1,5 +1,7 @@
 #include "ImageIO.h"
 
+#include "ImageFormats.h"
+
 #include <zlib.h>
 
 #include <cstdio>
@@ -138,11 +140,25 @@ bool unfilter(uint8_t* raw, size_t rowBytes, size_t rows, size_t bpp)
 
 const std::string& LastImageError() { return g_error; }
 
+static bool isPng(const std::vector<uint8_t>& file)
+{
+    static const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    return file.size() >= 8 && std::memcmp(file.data(), kSig, 8) == 0;
+}
+
 bool LoadImageInfoFromFile(const char* fileName, int& width, int& height, int& channels, int& reqChannels)
 {
     std::vector<uint8_t> file;
     PngHeader hdr;
-    if (!readFile(fileName, file) || !parseChunks(file, hdr, nullptr, nullptr, nullptr)) return false;
+    if (!readFile(fileName, file)) return false;
+    if (!isPng(file))      // the other formats stb_image accepts: BMP, binary PNM, TGA
+    {
+        std::string err;
+        if (!formats::Info(file, width, height, channels, err)) return fail(err);
+        reqChannels = channels != 3 ? channels : 4;
+        return true;
+    }
+    if (!parseChunks(file, hdr, nullptr, nullptr, nullptr)) return false;
     width = int(hdr.width);
     height = int(hdr.height);
     channels = fileChannels(hdr);
@@ -154,7 +170,23 @@ std::vector<uint8_t> LoadImageFromFile(const char* fileName, int& width, int& he
 {
     std::vector<uint8_t> file, idat, plte, trns;
     PngHeader hdr;
-    if (!readFile(fileName, file) || !parseChunks(file, hdr, &idat, &plte, &trns)) return {};
+    if (!readFile(fileName, file)) return {};
+    if (!isPng(file))
+    {
+        std::string err;
+        std::vector<uint8_t> px;
+        int channels = 0;
+        if (!formats::Decode(file, width, height, channels, px, err)) { fail(err); return {}; }
+        reqChannels = channels != 3 ? channels : 4;     // XUSGTextureLoader.h:20
+        if (channels != 3) return px;
+        std::vector<uint8_t> rgba(size_t(width) * height * 4);
+        for (size_t i = 0, n = size_t(width) * height; i < n; ++i)
+        {
+            rgba[4 * i] = px[3 * i]; rgba[4 * i + 1] = px[3 * i + 1]; rgba[4 * i + 2] = px[3 * i + 2]; rgba[4 * i + 3] = 255;
+        }
+        return rgba;
+    }
+    if (!parseChunks(file, hdr, &idat, &plte, &trns)) return {};
     const int spp = samplesPerPixel(hdr.colorType);
     const int depth = hdr.depth;
     const bool depthOk = (hdr.colorType == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
