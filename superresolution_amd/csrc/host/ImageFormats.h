@@ -1,4 +1,5 @@
-// BMP, TGA and binary PNM decoding (see ImageFormats.cpp); used by ImageIO for files that are not PNG.
+// BMP, TGA, binary PNM (ImageFormats.cpp) and baseline JPEG (ImageJpeg.cpp) decoding; used by ImageIO
+// for files that are not PNG.
 #pragma once
 
 #include <cstdint>
@@ -13,6 +14,12 @@ bool Info(const std::vector<uint8_t>& file, int& width, int& height, int& channe
 // The decoded pixels, `channels` interleaved bytes per pixel, rows top to bottom.
 bool Decode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
             std::string& err);
+
+// Baseline JPEG: 1 (grey) or 3 (RGB) channels.
+bool IsJpeg(const std::vector<uint8_t>& file);
+bool JpegInfo(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err);
+bool JpegDecode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
+                std::string& err);
 
 }  // namespace formats
 }  // namespace srx

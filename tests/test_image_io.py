@@ -210,3 +210,47 @@ def test_unsupported_flavours_are_refused(img, tmp_path):
         w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         assert img.srx_image_info(str(tmp_path / name).encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(req)) != 0
         assert b"not supported" in img.srx_image_last_error()
+
+
+@pytest.mark.parametrize("mode,size,kw", [("RGB", (43, 29), {"subsampling": 0}), ("RGB", (43, 29), {"subsampling": 1}),
+                                          ("RGB", (43, 29), {"subsampling": 2}), ("RGB", (64, 48), {"subsampling": 2, "quality": 95}),
+                                          ("RGB", (1, 1), {"subsampling": 2}), ("RGB", (17, 2), {"subsampling": 2, "quality": 30}),
+                                          ("L", (43, 29), {}), ("L", (8, 8), {"quality": 100}),
+                                          ("RGB", (131, 77), {"subsampling": 2, "optimize": True}),
+                                          ("RGB", (131, 77), {"subsampling": 1, "restart_marker_blocks": 3})])
+def test_baseline_jpeg_against_the_reference_decoder(img, oracle, tmp_path, mode, size, kw):
+    """Baseline JPEG as PIL (libjpeg) writes it, every chroma subsampling, odd sizes, optimised
+    Huffman tables, restart markers: the decoded bytes must equal the reference's stb_image, whose
+    inverse DCT, chroma upsampling and colour conversion this decoder restates.  Without the
+    compiled reference decoder only the plausibility of the result is checked."""
+    rng = np.random.default_rng(21)
+    w, h = size
+    n = 3 if mode == "RGB" else 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 5 + yy * 3 + 40 * k) % 256 for k in range(n)], axis=2)
+    a = ((smooth + rng.integers(0, 64, size=(h, w, n))) // 2 + 60).clip(0, 255).astype(np.uint8)
+    im = Image.fromarray(a[..., 0] if n == 1 else a, mode)
+    path = tmp_path / "t.jpg"
+    try:
+        im.save(path, format="JPEG", **kw)
+    except TypeError:
+        pytest.skip("this PIL cannot write that flavour")
+    got, ch, req = load(img, path)
+    assert (ch, req) == ((3, 4) if n == 3 else (1, 1)) and got.shape == (h, w, req)
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)
+    else:
+        d = got[..., :n].astype(float) - a
+        assert 10 * np.log10(255.0 ** 2 / max((d ** 2).mean(), 1e-9)) > 22.0
+
+
+def test_progressive_jpeg_is_refused(img, tmp_path):
+    im = Image.fromarray(np.random.default_rng(3).integers(0, 256, (16, 16, 3), dtype=np.uint8), "RGB")
+    path = tmp_path / "p.jpg"
+    im.save(path, format="JPEG", progressive=True)
+    w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    out = np.empty((16, 16, 4), np.uint8)
+    assert img.srx_image_load(str(path).encode(), out.ctypes.data, out.nbytes) != 0
+    assert b"rogressive" in img.srx_image_last_error()
