@@ -1,4 +1,4 @@
-// BMP, TGA, binary PNM (ImageFormats.cpp) and baseline JPEG (ImageJpeg.cpp) decoding; used by ImageIO
+// BMP, TGA, binary PNM (ImageFormats.cpp) and JPEG (ImageJpeg.cpp) decoding; used by ImageIO
 // for files that are not PNG.
 #pragma once
 
@@ -15,7 +15,7 @@ bool Info(const std::vector<uint8_t>& file, int& width, int& height, int& channe
 bool Decode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
             std::string& err);
 
-// Baseline JPEG: 1 (grey) or 3 (RGB) channels.
+// Baseline and progressive JPEG: 1 (grey) or 3 (RGB) channels.
 bool IsJpeg(const std::vector<uint8_t>& file);
 bool JpegInfo(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err);
 bool JpegDecode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,

@@ -1,4 +1,4 @@
-// Baseline (sequential Huffman, 8-bit) JPEG decoding for the host program's image loader.
+// Baseline and progressive (Huffman, 8-bit) JPEG decoding for the host program's image loader.
 //
 // The reference loads images through stb_image v2.30 (XUSG/Advanced/XUSGTextureLoader.h:17-32),
 // so "the decoded result" of a JPEG is what that decoder produces, and a JPEG decoder has choices
@@ -12,7 +12,10 @@
 //   * YCbCr -> RGB in 20-bit fixed point with the chroma products masked as in :3657-3683;
 //   * three-component files without a JFIF header whose Adobe marker says "no transform", or whose
 //     component ids are 'R','G','B', are RGB already (:3879).
-// Progressive, arithmetic-coded, 12-bit and four-component (CMYK / YCCK) files are refused.
+// A progressive file's coefficients are gathered over its scans (ITU T.81 G.1.2: spectral selection
+// and successive approximation), then multiplied by the quantisation table and transformed at the end,
+// as stb does (stb_image.h:2265-2420, 3025-3096).
+// Arithmetic-coded, 12-bit and four-component (CMYK / YCCK) files are refused.
 #include "ImageFormats.h"
 
 #include <cstring>
@@ -39,6 +42,7 @@ struct Component
     int x = 0, y = 0, w2 = 0, h2 = 0;       // true size in samples, allocated size (whole MCUs)
     int pred = 0;
     std::vector<uint8_t> data;
+    std::vector<short> coeff;               // progressive files: 64 coefficients per block, blocks row by row
 };
 
 struct Decoder
@@ -57,6 +61,9 @@ struct Decoder
     uint32_t bitBuf = 0;
     int bitCount = 0;
     bool hitMarker = false;
+    // progressive files
+    bool progressive = false;
+    int specStart = 0, specEnd = 63, succHigh = 0, succLow = 0, eobRun = 0;
 
     Decoder(const std::vector<uint8_t>& file, std::string& e) : f(file), err(e) {}
 
@@ -115,6 +122,7 @@ struct Decoder
         bitCount = 0;
         hitMarker = false;
         for (Component& c : comp) c.pred = 0;
+        eobRun = 0;
     }
 
     bool buildHuffman(Huffman& h, const int counts[16], const uint8_t* vals, int total)
@@ -222,6 +230,7 @@ struct Decoder
             c.w2 = mcuX * c.h * 8;
             c.h2 = mcuY * c.v * 8;
             c.data.assign(size_t(c.w2) * c.h2, 0);
+            if (progressive) c.coeff.assign(size_t(c.w2) * c.h2, 0);
         }
     }
 
@@ -317,6 +326,117 @@ struct Decoder
         return true;
     }
 
+    // Progressive DC scan: the first pass stores the prediction-coded value shifted up by the scan's low
+    // bit position, later passes append one bit each.
+    bool decodeBlockDc(Component& c, short d[64])
+    {
+        if (succHigh == 0)
+        {
+            const int t = decodeSymbol(dc[c.td]);
+            if (t < 0 || t > 15) return fail("JPEG: bad Huffman code");
+            c.pred += receiveExtend(t);
+            d[0] = short(c.pred * (1 << succLow));
+        }
+        else if (bit()) d[0] = short(d[0] + (1 << succLow));
+        return true;
+    }
+
+    // Progressive AC scan over coefficients specStart .. specEnd of one block.
+    bool decodeBlockAc(Component& c, short d[64])
+    {
+        const Huffman& h = ac[c.ta];
+        if (succHigh == 0)
+        {
+            if (eobRun) { --eobRun; return true; }
+            int k = specStart;
+            do
+            {
+                const int rs = decodeSymbol(h);
+                if (rs < 0) return fail("JPEG: bad Huffman code");
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0)
+                {
+                    if (r < 15)
+                    {
+                        eobRun = 1 << r;
+                        if (r) eobRun += bits(r);
+                        --eobRun;
+                        break;
+                    }
+                    k += 16;
+                }
+                else
+                {
+                    k += r;
+                    if (k > 63) return fail("JPEG: coefficient index out of range");
+                    d[kZigzag[k++]] = short(receiveExtend(s) * (1 << succLow));
+                }
+            } while (k <= specEnd);
+            return true;
+        }
+        // refinement: one more bit for every coefficient that is already non-zero, new +-1 coefficients between them
+        const int one = 1 << succLow;
+        const auto refine = [&](short& v) {
+            if (bit() && (v & one) == 0) v = short(v > 0 ? v + one : v - one);
+        };
+        if (eobRun)
+        {
+            --eobRun;
+            for (int k = specStart; k <= specEnd; ++k)
+                if (d[kZigzag[k]] != 0) refine(d[kZigzag[k]]);
+            return true;
+        }
+        int k = specStart;
+        do
+        {
+            const int rs = decodeSymbol(h);
+            if (rs < 0) return fail("JPEG: bad Huffman code");
+            int r = rs >> 4, s = rs & 15;
+            if (s == 0)
+            {
+                if (r < 15)
+                {
+                    eobRun = (1 << r) - 1;
+                    if (r) eobRun += bits(r);
+                    r = 64;          // run to the end of the band, refining on the way
+                }
+            }
+            else
+            {
+                if (s != 1) return fail("JPEG: bad refinement code");
+                s = bit() ? one : -one;
+            }
+            while (k <= specEnd)
+            {
+                short& v = d[kZigzag[k++]];
+                if (v != 0) refine(v);
+                else
+                {
+                    if (r == 0) { v = short(s); break; }
+                    --r;
+                }
+            }
+        } while (k <= specEnd);
+        return true;
+    }
+
+    // All scans of a progressive file read: quantisation scale and inverse transform of every block.
+    void finishProgressive()
+    {
+        for (int i = 0; i < numComp; ++i)
+        {
+            Component& c = comp[i];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3, stride = c.w2 >> 3;
+            for (int j = 0; j < bh; ++j)
+                for (int b = 0; b < bw; ++b)
+                {
+                    short* d = &c.coeff[(size_t(j) * stride + b) * 64];
+                    for (int k = 0; k < 64; ++k) d[k] = short(d[k] * dequant[c.tq][k]);
+                    idctBlock(&c.data[size_t(j) * 8 * c.w2 + size_t(b) * 8], c.w2, d);
+                }
+        }
+    }
+
     // After every restart interval the data must continue with an RSTn marker.
     bool restartIfDue(int& todo)
     {
@@ -344,16 +464,45 @@ struct Decoder
             if (which < 0) return fail("JPEG: scan names an unknown component");
             comp[which].td = q >> 4;
             comp[which].ta = q & 15;
-            if (comp[which].td > 3 || comp[which].ta > 3 || !dc[comp[which].td].present || !ac[comp[which].ta].present)
-                return fail("JPEG: scan uses a Huffman table that was not defined");
+            if (comp[which].td > 3 || comp[which].ta > 3) return fail("JPEG: bad Huffman table number");
             if (!haveQuant[comp[which].tq]) return fail("JPEG: component uses a quantisation table that was not defined");
             order[i] = which;
         }
-        const int ss = get8(), se = get8(), a = get8();
-        if (ss != 0 || se != 63 || a != 0) return fail("JPEG: progressive scans are not supported");
+        specStart = get8();
+        specEnd = get8();
+        const int a = get8();
+        succHigh = a >> 4;
+        succLow = a & 15;
+        if (!progressive)
+        {
+            if (specStart != 0 || specEnd != 63 || a != 0) return fail("JPEG: bad scan parameters in a sequential file");
+        }
+        else if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13 ||
+                 (specStart == 0 && specEnd != 0) || (specStart != 0 && n != 1))
+            return fail("JPEG: bad progressive scan parameters");
+        const bool dcScan = specStart == 0;
+        for (int i = 0; i < n; ++i)
+        {
+            const Component& c = comp[order[i]];
+            const bool needDc = !progressive || (dcScan && succHigh == 0), needAc = !progressive || !dcScan;
+            if ((needDc && !dc[c.td].present) || (needAc && !ac[c.ta].present))
+                return fail("JPEG: scan uses a Huffman table that was not defined");
+        }
         resetEntropy();
         int todo = restartInterval ? restartInterval : 0x7fffffff;
         short block[64];
+        // one block at (bx, by) of component c: a sequential file transforms it at once, a progressive one
+        // adds this scan's part to the stored coefficients
+        const auto oneBlock = [&](Component& c, int bx, int by) {
+            if (!progressive)
+            {
+                if (!decodeBlock(c, block)) return false;
+                idctBlock(&c.data[size_t(by) * 8 * c.w2 + size_t(bx) * 8], c.w2, block);
+                return true;
+            }
+            short* d = &c.coeff[(size_t(by) * (c.w2 >> 3) + bx) * 64];
+            return dcScan ? decodeBlockDc(c, d) : decodeBlockAc(c, d);
+        };
         if (n == 1)
         {
             // a scan of one component covers just its own blocks, row by row
@@ -362,8 +511,7 @@ struct Decoder
             for (int j = 0; j < bh; ++j)
                 for (int i = 0; i < bw; ++i)
                 {
-                    if (!decodeBlock(c, block)) return false;
-                    idctBlock(&c.data[size_t(j) * 8 * c.w2 + size_t(i) * 8], c.w2, block);
+                    if (!oneBlock(c, i, j)) return false;
                     restartIfDue(todo);
                 }
             return true;
@@ -376,10 +524,7 @@ struct Decoder
                     Component& c = comp[order[k]];
                     for (int y = 0; y < c.v; ++y)
                         for (int x = 0; x < c.h; ++x)
-                        {
-                            if (!decodeBlock(c, block)) return false;
-                            idctBlock(&c.data[size_t(my * c.v + y) * 8 * c.w2 + size_t(mx * c.h + x) * 8], c.w2, block);
-                        }
+                            if (!oneBlock(c, mx * c.h + x, my * c.v + y)) return false;
                 }
                 restartIfDue(todo);
             }
@@ -401,15 +546,15 @@ struct Decoder
             const int m = f[pos++];
             if (m == 0xd9) break;                                   // EOI
             if (m == 0x00 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;
-            if (m == 0xc0 || m == 0xc1)
+            if (m == 0xc0 || m == 0xc1 || m == 0xc2)
             {
+                progressive = m == 0xc2;
                 if (haveFrame) return fail("JPEG: more than one frame");
                 if (!frameHeader()) return false;
                 haveFrame = true;
                 if (stopAtFrame) return true;
                 allocate();
             }
-            else if (m == 0xc2) return fail("JPEG: progressive files are not supported");
             else if ((m >= 0xc3 && m <= 0xcf) && m != 0xc4 && m != 0xc8 && m != 0xcc)
                 return fail("JPEG: lossless, hierarchical and arithmetic-coded files are not supported");
             else if (m == 0xcc) return fail("JPEG: arithmetic-coded files are not supported");
@@ -423,6 +568,7 @@ struct Decoder
         }
         if (!haveFrame) return fail("JPEG: no frame header");
         if (!stopAtFrame && !haveScan) return fail("JPEG: no scan");
+        if (!stopAtFrame && progressive) finishProgressive();
         return true;
     }
 

@@ -246,11 +246,38 @@ def test_baseline_jpeg_against_the_reference_decoder(img, oracle, tmp_path, mode
         assert 10 * np.log10(255.0 ** 2 / max((d ** 2).mean(), 1e-9)) > 22.0
 
 
-def test_progressive_jpeg_is_refused(img, tmp_path):
-    im = Image.fromarray(np.random.default_rng(3).integers(0, 256, (16, 16, 3), dtype=np.uint8), "RGB")
+@pytest.mark.parametrize("mode,size,kw", [("RGB", (43, 29), {"subsampling": 0}), ("RGB", (131, 77), {"subsampling": 2}),
+                                          ("RGB", (64, 64), {"subsampling": 1, "quality": 95}), ("L", (57, 33), {}),
+                                          ("RGB", (1, 1), {}), ("RGB", (200, 120), {"subsampling": 2, "quality": 20}),
+                                          ("RGB", (131, 77), {"subsampling": 2, "restart_marker_blocks": 2})])
+def test_progressive_jpeg_against_the_reference_decoder(img, oracle, tmp_path, mode, size, kw):
+    """Progressive files (spectral selection and successive approximation, as libjpeg's default scan
+    script writes them): byte-identical to the reference's stb_image."""
+    rng = np.random.default_rng(22)
+    w, h = size
+    n = 3 if mode == "RGB" else 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 7 + yy * 2 + 50 * k) % 256 for k in range(n)], axis=2)
+    a = ((smooth + rng.integers(0, 96, size=(h, w, n))) // 2 + 40).clip(0, 255).astype(np.uint8)
+    im = Image.fromarray(a[..., 0] if n == 1 else a, mode)
     path = tmp_path / "p.jpg"
-    im.save(path, format="JPEG", progressive=True)
-    w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    im.save(path, format="JPEG", progressive=True, **kw)
+    assert b"\xff\xc2" in path.read_bytes()
+    got, ch, req = load(img, path)
+    assert (ch, req) == ((3, 4) if n == 3 else (1, 1)) and got.shape == (h, w, req)
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)
+    else:
+        d = got[..., :n].astype(float) - a
+        assert 10 * np.log10(255.0 ** 2 / max((d ** 2).mean(), 1e-9)) > 20.0
+
+
+def test_unsupported_jpeg_flavours_are_refused(img, tmp_path):
+    im = Image.fromarray(np.random.default_rng(3).integers(0, 256, (16, 16, 4), dtype=np.uint8), "CMYK")
+    path = tmp_path / "cmyk.jpg"
+    im.save(path, format="JPEG")
     out = np.empty((16, 16, 4), np.uint8)
     assert img.srx_image_load(str(path).encode(), out.ctypes.data, out.nbytes) != 0
-    assert b"rogressive" in img.srx_image_last_error()
+    assert b"CMYK" in img.srx_image_last_error()
