@@ -1,5 +1,7 @@
 #include "SuperResolutionX.h"
 
+#include <cwchar>
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -153,11 +155,13 @@ void SuperResolutionX::ParseCommandLineArgs(wchar_t* argv[], int argc)
         return (arg[0] == L'-' || arg[0] == L'/') && lower(arg + 1) == lower(name);
     };
     // a value is anything that is not itself a switch; "-1" and "-.5" count as values
+    // (SuperResolutionX.cpp:304-310).  There a leading '/' always marks a switch; here it also starts
+    // an absolute path, so "/x" is a value when it goes on like a path (another '/' or a '.' in it).
     const auto hasValue = [&](int i)
     {
         if (i + 1 >= argc) return false;
         const wchar_t* arg = argv[i + 1];
-        if (arg[0] == L'/') return false;
+        if (arg[0] == L'/') return wcschr(arg + 1, L'/') != nullptr || wcschr(arg + 1, L'.') != nullptr;
         return arg[0] != L'-' || (arg[1] >= L'0' && arg[1] <= L'9') || arg[1] == L'.';
     };
 

@@ -84,3 +84,23 @@ def test_fp32_and_nhwc_switches(workdir, switches):
     with S.SuperResolutionContext(128, 128) as ctx:
         fast = ctx.run(load_png_rgba(os.path.join(ASSETS, "Sashimi128.png")))[..., :3].astype(int)
     assert (np.abs(got - fast) <= 1).mean() >= 0.999
+
+
+@pytest.mark.parametrize("ext,kw", [("jpg", {"quality": 90, "subsampling": 2}), ("jpg", {"progressive": True}), ("bmp", {}), ("tga", {})])
+def test_other_input_formats(workdir, ext, kw):
+    """-i with the other formats the reference's loader accepts: the program upscales what the loader
+    decodes (the decoders themselves are pinned against the reference's in tests/test_image_io.py)."""
+    import ctypes as C
+    src = Image.open(os.path.join(ASSETS, "Sashimi128.png")).convert("RGB")
+    path = workdir / f"in.{ext}"
+    src.save(path, **kw)
+    r = run(["-i", str(path), "-o", "o.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "output 256x256" in r.stdout
+    L = C.CDLL(os.path.join(ROOT, "superresolution_amd", "libsrximage.so"))
+    L.srx_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+    rgba = np.empty((128, 128, 4), np.uint8)
+    assert L.srx_image_load(str(path).encode(), rgba.ctypes.data, rgba.nbytes) == 0
+    with S.SuperResolutionContext(128, 128) as ctx:
+        want = ctx.run(rgba)
+    assert np.array_equal(np.asarray(Image.open(workdir / "o.png")), want[..., :3])
