@@ -8,6 +8,7 @@
 // TGA, 16-bit PNM) is refused with a message rather than guessed at.
 #include "ImageFormats.h"
 
+#include <cstdint>
 #include <cstring>
 
 namespace srx {
@@ -53,6 +54,7 @@ bool parseBmp(const std::vector<uint8_t>& f, BmpHeader& h, std::string& err)
         h.colorsUsed = le32(&f[46]);
     }
     h.bottomUp = h.height > 0;
+    if (h.height == INT32_MIN) return setError(err, "BMP: bad size");
     if (h.height < 0) h.height = -h.height;
     if (h.width <= 0 || h.height <= 0 || h.width > (1 << 24) || h.height > (1 << 24)) return setError(err, "BMP: bad size");
     if (h.compression != 0) return setError(err, "BMP: compressed and bit-field files are not supported");

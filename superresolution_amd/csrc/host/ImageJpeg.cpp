@@ -234,28 +234,33 @@ struct Decoder
         }
     }
 
-    static uint8_t clamp(int x) { return uint8_t(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+    // a DC value of a valid file fits 16 bits; the bound only keeps damaged files inside int
+    static int boundedPred(int v) { return v < -(1 << 20) ? -(1 << 20) : (v > (1 << 20) ? (1 << 20) : v); }
+    static uint8_t clamp(long long x) { return uint8_t(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
     // One pass of the jidctint-style 1-D transform on eight values: even part x0..x3, odd part t0..t3.
-    static void idct1d(const int s[8], int x[4], int t[4])
+    // 64-bit intermediates: a valid file stays far inside 32 bits (where stb computes), a damaged one
+    // must not overflow.
+    typedef long long wide;
+    static void idct1d(const wide s[8], wide x[4], wide t[4])
     {
         // the constants are float literals scaled by 4096 and rounded by adding 0.5 and truncating
         // (so the negative ones round toward zero from one half above), as in stb_image.h:2426
         constexpr auto f2f = [](float v) { return int(v * 4096 + 0.5); };
-        int p2 = s[2], p3 = s[6];
-        int p1 = (p2 + p3) * f2f(0.5411961f);
-        const int t2e = p1 + p3 * f2f(-1.847759065f);
-        const int t3e = p1 + p2 * f2f(0.765366865f);
+        wide p2 = s[2], p3 = s[6];
+        wide p1 = (p2 + p3) * f2f(0.5411961f);
+        const wide t2e = p1 + p3 * f2f(-1.847759065f);
+        const wide t3e = p1 + p2 * f2f(0.765366865f);
         p2 = s[0];
         p3 = s[4];
-        const int t0e = (p2 + p3) * 4096, t1e = (p2 - p3) * 4096;
+        const wide t0e = (p2 + p3) * 4096, t1e = (p2 - p3) * 4096;
         x[0] = t0e + t3e; x[3] = t0e - t3e; x[1] = t1e + t2e; x[2] = t1e - t2e;
-        int t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
+        wide t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
         p3 = t0 + t2;
-        int p4 = t1 + t3;
+        wide p4 = t1 + t3;
         p1 = t0 + t3;
         p2 = t1 + t2;
-        const int p5 = (p3 + p4) * f2f(1.175875602f);
+        const wide p5 = (p3 + p4) * f2f(1.175875602f);
         t0 = t0 * f2f(0.298631336f);
         t1 = t1 * f2f(2.053119869f);
         t2 = t2 * f2f(3.072711026f);
@@ -269,7 +274,7 @@ struct Decoder
 
     static void idctBlock(uint8_t* out, int stride, const short d[64])
     {
-        int val[64];
+        wide val[64];
         for (int i = 0; i < 8; ++i)
         {
             if (!d[i + 8] && !d[i + 16] && !d[i + 24] && !d[i + 32] && !d[i + 40] && !d[i + 48] && !d[i + 56])
@@ -277,8 +282,8 @@ struct Decoder
                 for (int r = 0; r < 8; ++r) val[i + 8 * r] = d[i] * 4;
                 continue;
             }
-            const int s[8] = {d[i], d[i + 8], d[i + 16], d[i + 24], d[i + 32], d[i + 40], d[i + 48], d[i + 56]};
-            int x[4], t[4];
+            const wide s[8] = {d[i], d[i + 8], d[i + 16], d[i + 24], d[i + 32], d[i + 40], d[i + 48], d[i + 56]};
+            wide x[4], t[4];
             idct1d(s, x, t);
             for (int k = 0; k < 4; ++k) x[k] += 512;
             val[i] = (x[0] + t[3]) >> 10;      val[i + 56] = (x[0] - t[3]) >> 10;
@@ -288,7 +293,7 @@ struct Decoder
         }
         for (int r = 0; r < 8; ++r, out += stride)
         {
-            int x[4], t[4];
+            wide x[4], t[4];
             idct1d(val + 8 * r, x, t);
             for (int k = 0; k < 4; ++k) x[k] += 65536 + (128 << 17);
             out[0] = clamp((x[0] + t[3]) >> 17); out[7] = clamp((x[0] - t[3]) >> 17);
@@ -303,8 +308,8 @@ struct Decoder
         std::memset(d, 0, 64 * sizeof(short));
         const int t = decodeSymbol(dc[c.td]);
         if (t < 0 || t > 15) return fail("JPEG: bad Huffman code");
-        c.pred += receiveExtend(t);
-        d[0] = short(c.pred * dequant[c.tq][0]);
+        c.pred = boundedPred(c.pred + receiveExtend(t));
+        d[0] = short((long long)c.pred * dequant[c.tq][0]);
         for (int k = 1; k < 64;)
         {
             const int rs = decodeSymbol(ac[c.ta]);
@@ -334,8 +339,8 @@ struct Decoder
         {
             const int t = decodeSymbol(dc[c.td]);
             if (t < 0 || t > 15) return fail("JPEG: bad Huffman code");
-            c.pred += receiveExtend(t);
-            d[0] = short(c.pred * (1 << succLow));
+            c.pred = boundedPred(c.pred + receiveExtend(t));
+            d[0] = short((long long)c.pred * (1 << succLow));
         }
         else if (bit()) d[0] = short(d[0] + (1 << succLow));
         return true;
@@ -431,7 +436,7 @@ struct Decoder
                 for (int b = 0; b < bw; ++b)
                 {
                     short* d = &c.coeff[(size_t(j) * stride + b) * 64];
-                    for (int k = 0; k < 64; ++k) d[k] = short(d[k] * dequant[c.tq][k]);
+                    for (int k = 0; k < 64; ++k) d[k] = short((long long)d[k] * dequant[c.tq][k]);
                     idctBlock(&c.data[size_t(j) * 8 * c.w2 + size_t(b) * 8], c.w2, d);
                 }
         }
