@@ -146,10 +146,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    shared = world > torch.cuda.device_count()    # more ranks than GPUs: a rehearsal of the N > 1 path on fewer GPUs
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared:      # RCCL refuses two ranks on one GPU; the barrier and the max-reduce then go over gloo
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import superresolution_amd as S
     B = args.batch
@@ -245,6 +250,8 @@ def main():
                                  "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                                  "(tools/mfma_shape_bench.hip)"},
         }
+        if shared:
+            out["rehearsal"] = f"{world} ranks on {torch.cuda.device_count()} GPU(s): not a scaling measurement"
         info = ctx.device_info()
         out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "max_clock_mhz": info["clock_khz"] // 1000,
                          "peak_note": "2.5 PFLOP/s = 256 CUs x 4096 fp16 FLOP/clk x 2.4 GHz"}
