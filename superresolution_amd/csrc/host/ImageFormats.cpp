@@ -242,6 +242,7 @@ bool isPnm(const std::vector<uint8_t>& f) { return f.size() >= 2 && f[0] == 'P' 
 bool Info(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err)
 {
     if (IsJpeg(file)) return JpegInfo(file, width, height, channels, err);
+    if (IsGif(file)) return GifInfo(file, width, height, channels, err);
     if (isBmp(file))
     {
         BmpHeader h;
@@ -265,6 +266,7 @@ bool Info(const std::vector<uint8_t>& file, int& width, int& height, int& channe
 bool Decode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels, std::string& err)
 {
     if (IsJpeg(file)) return JpegDecode(file, width, height, channels, pixels, err);
+    if (IsGif(file)) return GifDecode(file, width, height, channels, pixels, err);
     if (isBmp(file))
     {
         BmpHeader h;

@@ -1,4 +1,4 @@
-// BMP, TGA, binary PNM (ImageFormats.cpp) and JPEG (ImageJpeg.cpp) decoding; used by ImageIO
+// BMP, TGA, binary PNM (ImageFormats.cpp) JPEG (ImageJpeg.cpp) and GIF (ImageGif.cpp) decoding; used by ImageIO
 // for files that are not PNG.
 #pragma once
 
@@ -20,6 +20,12 @@ bool IsJpeg(const std::vector<uint8_t>& file);
 bool JpegInfo(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err);
 bool JpegDecode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
                 std::string& err);
+
+// GIF: the first image composed on the logical screen, 4 channels.
+bool IsGif(const std::vector<uint8_t>& file);
+bool GifInfo(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::string& err);
+bool GifDecode(const std::vector<uint8_t>& file, int& width, int& height, int& channels, std::vector<uint8_t>& pixels,
+               std::string& err);
 
 }  // namespace formats
 }  // namespace srx

@@ -140,6 +140,9 @@ bool unfilter(uint8_t* raw, size_t rowBytes, size_t rows, size_t bpp)
 
 const std::string& LastImageError() { return g_error; }
 
+// Larger than anything the upscaler accepts (2^27 pixels); keeps a damaged header from asking for terabytes.
+static constexpr uint64_t kMaxPixels = uint64_t(1) << 28;
+
 static bool isPng(const std::vector<uint8_t>& file)
 {
     static const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
@@ -176,6 +179,8 @@ std::vector<uint8_t> LoadImageFromFile(const char* fileName, int& width, int& he
         std::string err;
         std::vector<uint8_t> px;
         int channels = 0;
+        if (!formats::Info(file, width, height, channels, err)) { fail(err); return {}; }
+        if (uint64_t(width) * uint64_t(height) > kMaxPixels) { fail("image too large"); return {}; }
         if (!formats::Decode(file, width, height, channels, px, err)) { fail(err); return {}; }
         reqChannels = channels != 3 ? channels : 4;     // XUSGTextureLoader.h:20
         if (channels != 3) return px;
@@ -187,6 +192,7 @@ std::vector<uint8_t> LoadImageFromFile(const char* fileName, int& width, int& he
         return rgba;
     }
     if (!parseChunks(file, hdr, &idat, &plte, &trns)) return {};
+    if (uint64_t(hdr.width) * uint64_t(hdr.height) > kMaxPixels) { fail("image too large"); return {}; }
     const int spp = samplesPerPixel(hdr.colorType);
     const int depth = hdr.depth;
     const bool depthOk = (hdr.colorType == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||

@@ -1,4 +1,4 @@
-// Headless image I/O for the super-resolution host program: PNG (and BMP, TGA, binary PNM, JPEG) in, PNG out.
+// Headless image I/O for the super-resolution host program: PNG (and BMP, TGA, binary PNM, GIF, JPEG) in, PNG out.
 //
 // Takes the place of the stb-based loader / writer the reference calls
 // (XUSG/Advanced/XUSGTextureLoader.h:17-32 -> stbi_info + stbi_load;

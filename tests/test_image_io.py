@@ -281,3 +281,55 @@ def test_unsupported_jpeg_flavours_are_refused(img, tmp_path):
     out = np.empty((16, 16, 4), np.uint8)
     assert img.srx_image_load(str(path).encode(), out.ctypes.data, out.nbytes) != 0
     assert b"CMYK" in img.srx_image_last_error()
+
+
+def _gif(tmp_path, name, w=37, h=23, colors=19, **kw):
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    a[:6, :11] = a[0, 0]
+    im = Image.fromarray(a, "RGB").quantize(colors)
+    path = tmp_path / name
+    im.save(path, format="GIF", **kw)
+    return path
+
+
+@pytest.mark.parametrize("kw", [{}, {"interlace": 1}, {"interlace": 0}, {"transparency": 3}, {"transparency": 0, "interlace": 1},
+                                {"colors": 2}, {"colors": 256, "w": 130, "h": 70}])
+def test_gif_against_the_reference_decoder(img, oracle, tmp_path, kw):
+    """The first image of a GIF as RGBA: palette sizes, interlacing, a transparent index."""
+    kw = dict(kw)
+    size = {k: kw.pop(k) for k in ("w", "h", "colors") if k in kw}
+    path = _gif(tmp_path, "t.gif", **size, **kw)
+    got, ch, req = load(img, path)
+    assert (ch, req) == (4, 4)
+    pil = np.asarray(Image.open(path).convert("RGBA"))
+    opaque = got[..., 3] == 255
+    assert np.array_equal(got[opaque], pil[opaque]) and (got[~opaque] == 0).all()
+    if "transparency" in kw:
+        assert (~opaque).any()
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)
+
+
+def test_gif_smaller_than_its_screen(img, oracle, tmp_path):
+    """An image that does not cover the logical screen, with a background index: the pixels outside
+    its rectangle get the background palette entry the way the reference's decoder writes it."""
+    import struct
+    path = _gif(tmp_path, "s.gif", w=20, h=12, colors=8, interlace=0)
+    d = bytearray(path.read_bytes())
+    d[6:10] = struct.pack("<HH", 26, 17)       # logical screen larger than the image
+    d[11] = 5                                   # background colour index
+    at = d.index(b"\x2c", 13 + 3 * (2 << (d[10] & 7)))
+    d[at + 1:at + 5] = struct.pack("<HH", 4, 3)
+    path.write_bytes(d)
+    got, ch, req = load(img, path)
+    assert got.shape == (17, 26, 4)
+    inside = np.zeros((17, 26), bool)
+    inside[3:15, 4:24] = True
+    assert (got[~inside] == got[0, 0]).all() and got[0, 0, 3] == 255
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)

@@ -25,7 +25,7 @@ SAN = ["-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize
 
 def build():
     subprocess.check_call(["g++"] + SAN + ["-I" + HOST, "-o", "/tmp/fuzz_decode_image", os.path.join(HERE, "decode_image.cpp")] +
-                          [os.path.join(HOST, f) for f in ("ImageIO.cpp", "ImageFormats.cpp", "ImageJpeg.cpp")] + ["-lz"])
+                          [os.path.join(HOST, f) for f in ("ImageIO.cpp", "ImageFormats.cpp", "ImageJpeg.cpp", "ImageGif.cpp")] + ["-lz"])
     subprocess.check_call(["g++"] + SAN + ["-I" + CSRC, "-o", "/tmp/fuzz_load_weights", os.path.join(HERE, "load_weights.cpp"),
                            os.path.join(CSRC, "srx_weights.cpp")])
 
@@ -66,7 +66,7 @@ def main():
     seeds = {}
     for name, fmt, kw in (("s.png", "PNG", {}), ("s.jpg", "JPEG", {"quality": 80, "subsampling": 2}),
                           ("sp.jpg", "JPEG", {"progressive": True, "subsampling": 1}), ("sr.jpg", "JPEG", {"restart_marker_blocks": 2}),
-                          ("s.bmp", "BMP", {}), ("s.tga", "TGA", {}), ("sr.tga", "TGA", {"compression": "tga_rle"}), ("s.ppm", "PPM", {})):
+                          ("s.gif", "GIF", {}), ("st.gif", "GIF", {"transparency": 2, "interlace": 1}), ("s.bmp", "BMP", {}), ("s.tga", "TGA", {}), ("sr.tga", "TGA", {"compression": "tga_rle"}), ("s.ppm", "PPM", {})):
         b = io.BytesIO()
         im.save(b, format=fmt, **kw)
         seeds[name] = b.getvalue()
