@@ -3,9 +3,9 @@
 // The reference loads images through stb_image (XUSG/Advanced/XUSGTextureLoader.h:17-32 ->
 // stbi_info + stbi_load), which accepts these formats beside PNG.  The contract kept here is the
 // decoded result of the common, uncompressed (and TGA run-length) flavours: 8 bits per channel,
-// rows top to bottom, channel count as stb reports it (BMP: 3, or 4 for 32-bit files; TGA: 1, 3
-// or 4; PNM: 1 or 3).  What is not handled (BMP bit fields / RLE / 16-bit, palette TGA, 15/16-bit
-// TGA, 16-bit PNM) is refused with a message rather than guessed at.
+// rows top to bottom, channel count as stb reports it (BMP: 3, or 4 for 32-bit files; TGA: 1,
+// 2 (grey + alpha), 3 or 4, also through a colour map; PNM: 1 or 3).  What is not handled (BMP bit
+// fields / RLE / 16-bit, 15/16-bit colour TGA, 16-bit PNM) is refused with a message rather than guessed at.
 #include "ImageFormats.h"
 
 #include <cstdint>
@@ -58,18 +58,19 @@ bool parseBmp(const std::vector<uint8_t>& f, BmpHeader& h, std::string& err)
     if (h.height < 0) h.height = -h.height;
     if (h.width <= 0 || h.height <= 0 || h.width > (1 << 24) || h.height > (1 << 24)) return setError(err, "BMP: bad size");
     if (h.compression != 0) return setError(err, "BMP: compressed and bit-field files are not supported");
-    if (h.bpp != 8 && h.bpp != 24 && h.bpp != 32) return setError(err, "BMP: only 8-, 24- and 32-bit files are supported");
+    if (h.bpp != 1 && h.bpp != 4 && h.bpp != 8 && h.bpp != 24 && h.bpp != 32)
+        return setError(err, "BMP: 16-bit files are not supported");
     return true;
 }
 
 bool decodeBmp(const std::vector<uint8_t>& f, const BmpHeader& h, std::vector<uint8_t>& out, int channels, std::string& err)
 {
     const size_t W = size_t(h.width), H = size_t(h.height);
-    const size_t rowBytes = (W * h.bpp / 8 + 3) & ~size_t(3);
+    const size_t rowBytes = ((W * h.bpp + 7) / 8 + 3) & ~size_t(3);
     if (h.dataOffset > f.size() || rowBytes * H > f.size() - h.dataOffset) return setError(err, "BMP: pixel data is short");
     const uint8_t* palette = nullptr;
-    size_t paletteEntry = 4;
-    if (h.bpp == 8)
+    size_t paletteEntry = 4, paletteCount = 0;
+    if (h.bpp <= 8)
     {
         const size_t at = 14 + h.headerSize;
         paletteEntry = h.headerSize == 12 ? 3 : 4;
@@ -77,6 +78,7 @@ bool decodeBmp(const std::vector<uint8_t>& f, const BmpHeader& h, std::vector<ui
         if (h.headerSize == 12 || !h.colorsUsed) n = (h.dataOffset - at) / paletteEntry;     // as many as lie before the pixels
         if (n == 0 || n > 256 || at + n * paletteEntry > f.size()) return setError(err, "BMP: bad palette");
         palette = &f[at];
+        paletteCount = n;
     }
     out.assign(W * H * size_t(channels), 255);
     bool anyAlpha = false;
@@ -86,9 +88,14 @@ bool decodeBmp(const std::vector<uint8_t>& f, const BmpHeader& h, std::vector<ui
         uint8_t* dst = &out[y * W * size_t(channels)];
         for (size_t x = 0; x < W; ++x, dst += channels)
         {
-            if (h.bpp == 8)
+            if (h.bpp <= 8)
             {
-                const uint8_t* e = palette + size_t(src[x]) * paletteEntry;
+                // 1- and 4-bit indices are packed most significant first
+                size_t idx = src[x];
+                if (h.bpp == 4) idx = (src[x >> 1] >> ((x & 1) ? 0 : 4)) & 15;
+                else if (h.bpp == 1) idx = (src[x >> 3] >> (7 - (x & 7))) & 1;
+                if (idx >= paletteCount) idx = 0;
+                const uint8_t* e = palette + idx * paletteEntry;
                 dst[0] = e[2]; dst[1] = e[1]; dst[2] = e[0];
             }
             else
@@ -154,8 +161,9 @@ bool decodePnm(const std::vector<uint8_t>& f, const PnmHeader& h, std::vector<ui
 struct TgaHeader
 {
     int idLength = 0, colorMapType = 0, imageType = 0, width = 0, height = 0, bpp = 0, descriptor = 0;
-    int channels = 0;
-    bool rle = false;
+    int paletteStart = 0, paletteLength = 0, paletteBits = 0;
+    int channels = 0;      // of the decoded image: the palette's for a colour-mapped file
+    bool rle = false, indexed = false;
 };
 
 bool parseTga(const std::vector<uint8_t>& f, TgaHeader& h, std::string& err)
@@ -164,31 +172,54 @@ bool parseTga(const std::vector<uint8_t>& f, TgaHeader& h, std::string& err)
     h.idLength = f[0];
     h.colorMapType = f[1];
     h.imageType = f[2];
+    h.paletteStart = int(le16(&f[3]));
+    h.paletteLength = int(le16(&f[5]));
+    h.paletteBits = f[7];
     h.width = int(le16(&f[12]));
     h.height = int(le16(&f[14]));
     h.bpp = f[16];
     h.descriptor = f[17];
     h.rle = h.imageType >= 8;
+    h.indexed = h.colorMapType == 1;
     const int base = h.imageType & 7;
-    if (h.colorMapType > 1 || (base != 1 && base != 2 && base != 3) || (h.imageType & ~11) != 0 || h.width <= 0 || h.height <= 0)
+    if (h.colorMapType > 1 || (base != 1 && base != 2 && base != 3) || (h.imageType & ~11) != 0 || h.width <= 0 || h.height <= 0 ||
+        (h.indexed != (base == 1)))
         return setError(err, "unknown image type");      // not a TGA either
-    if (h.colorMapType == 1 || base == 1) return setError(err, "TGA: colour-mapped files are not supported");
-    if (base == 3 && h.bpp == 8) h.channels = 1;
+    if (h.indexed)
+    {
+        if (h.bpp != 8 && h.bpp != 16) return setError(err, "TGA: colour-map indices must be 8 or 16 bits");
+        if (h.paletteBits == 24 || h.paletteBits == 32) h.channels = h.paletteBits / 8;
+        else return setError(err, "TGA: only 24- and 32-bit colour maps are supported");
+        if (h.paletteLength == 0) return setError(err, "TGA: empty colour map");
+    }
+    else if (base == 3 && h.bpp == 8) h.channels = 1;
+    else if (base == 3 && h.bpp == 16) h.channels = 2;      // grey + alpha
     else if (base == 2 && h.bpp == 24) h.channels = 3;
     else if (base == 2 && h.bpp == 32) h.channels = 4;
-    else return setError(err, "TGA: only 8-bit grey, 24- and 32-bit true-colour files are supported");
+    else return setError(err, "TGA: 15- and 16-bit colour files are not supported");
     return true;
 }
 
 bool decodeTga(const std::vector<uint8_t>& f, const TgaHeader& h, std::vector<uint8_t>& out, std::string& err)
 {
     const size_t W = size_t(h.width), H = size_t(h.height), C = size_t(h.channels), n = W * H;
+    const size_t S = h.indexed ? size_t(h.bpp / 8) : C;      // bytes per stored pixel
     size_t p = 18 + size_t(h.idLength);
-    std::vector<uint8_t> px(n * C);
+    const uint8_t* palette = nullptr;
+    if (h.indexed)
+    {
+        // the reference's decoder skips "first entry index" BYTES before the map (stb_image.h:5949); so does this
+        p += size_t(h.paletteStart);
+        const size_t bytes = size_t(h.paletteLength) * C;
+        if (p > f.size() || bytes > f.size() - p) return setError(err, "TGA: colour map is short");
+        palette = &f[p];
+        p += bytes;
+    }
+    std::vector<uint8_t> raw(n * S);
     if (!h.rle)
     {
-        if (p > f.size() || n * C > f.size() - p) return setError(err, "TGA: pixel data is short");
-        std::memcpy(px.data(), &f[p], n * C);
+        if (p > f.size() || n * S > f.size() - p) return setError(err, "TGA: pixel data is short");
+        std::memcpy(raw.data(), &f[p], n * S);
     }
     else
     {
@@ -201,15 +232,15 @@ bool decodeTga(const std::vector<uint8_t>& f, const TgaHeader& h, std::vector<ui
             if (count > n - i) count = n - i;
             if (packet & 128)
             {
-                if (C > f.size() - p) return setError(err, "TGA: pixel data is short");
-                for (size_t k = 0; k < count; ++k) std::memcpy(&px[(i + k) * C], &f[p], C);
-                p += C;
+                if (S > f.size() - p) return setError(err, "TGA: pixel data is short");
+                for (size_t k = 0; k < count; ++k) std::memcpy(&raw[(i + k) * S], &f[p], S);
+                p += S;
             }
             else
             {
-                if (count * C > f.size() - p) return setError(err, "TGA: pixel data is short");
-                std::memcpy(&px[i * C], &f[p], count * C);
-                p += count * C;
+                if (count * S > f.size() - p) return setError(err, "TGA: pixel data is short");
+                std::memcpy(&raw[i * S], &f[p], count * S);
+                p += count * S;
             }
             i += count;
         }
@@ -219,15 +250,22 @@ bool decodeTga(const std::vector<uint8_t>& f, const TgaHeader& h, std::vector<ui
     out.resize(n * C);
     for (size_t y = 0; y < H; ++y)
     {
-        const uint8_t* src = &px[(bottomUp ? H - 1 - y : y) * W * C];
+        const uint8_t* src = &raw[(bottomUp ? H - 1 - y : y) * W * S];
         uint8_t* dst = &out[y * W * C];
-        for (size_t x = 0; x < W; ++x, src += C, dst += C)
+        for (size_t x = 0; x < W; ++x, src += S, dst += C)
         {
-            if (C == 1) dst[0] = src[0];
+            const uint8_t* e = src;
+            if (h.indexed)
+            {
+                size_t idx = S == 1 ? src[0] : le16(src);
+                if (idx >= size_t(h.paletteLength)) idx = 0;      // an index beyond the map reads entry 0
+                e = palette + idx * C;
+            }
+            if (C <= 2) { dst[0] = e[0]; if (C == 2) dst[1] = e[1]; }
             else
             {
-                dst[0] = src[2]; dst[1] = src[1]; dst[2] = src[0];
-                if (C == 4) dst[3] = src[3];
+                dst[0] = e[2]; dst[1] = e[1]; dst[2] = e[0];
+                if (C == 4) dst[3] = e[3];
             }
         }
     }

@@ -201,15 +201,62 @@ def test_pnm_with_comments(img, oracle, tmp_path):
 
 def test_unsupported_flavours_are_refused(img, tmp_path):
     import struct
-    # a BMP with bit fields (compression 3) and a colour-mapped TGA: refused with a reason, not guessed at
+    # a BMP with bit fields (compression 3) and a 16-bit colour TGA: refused with a reason, not guessed at
     bmp = b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 2, 2, 1, 16, 3, 16, 0, 0, 0, 0) + bytes(16)
     (tmp_path / "bf.bmp").write_bytes(bmp)
-    tga = bytes([0, 1, 1, 0, 0, 2, 0, 24, 0, 0, 0, 0, 2, 0, 2, 0, 8, 0]) + bytes(6 + 4)
-    (tmp_path / "cm.tga").write_bytes(tga)
-    for name in ("bf.bmp", "cm.tga"):
+    tga = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 2, 0, 16, 0]) + bytes(8)
+    (tmp_path / "hi.tga").write_bytes(tga)
+    for name in ("bf.bmp", "hi.tga"):
         w, h, ch, req = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         assert img.srx_image_info(str(tmp_path / name).encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(req)) != 0
         assert b"not supported" in img.srx_image_last_error()
+
+
+@pytest.mark.parametrize("ext,mode,kw", [("tga", "P", {}), ("tga", "P", {"compression": "tga_rle"}), ("tga", "LA", {}), ("bmp", "1", {})])
+def test_palette_and_grey_alpha_flavours(img, oracle, tmp_path, ext, mode, kw):
+    """Colour-mapped TGA, grey + alpha TGA and 1-bit BMP as PIL writes them, against the reference's stb_image."""
+    rng = np.random.default_rng(13)
+    h, w = 19, 37
+    if mode == "P":
+        im = Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "RGB").quantize(29)
+    elif mode == "LA":
+        im = Image.fromarray(rng.integers(0, 256, size=(h, w, 2), dtype=np.uint8), "LA")
+    else:
+        im = Image.fromarray((rng.integers(0, 2, size=(h, w)) * 255).astype(np.uint8)).convert("1")
+    path = tmp_path / f"t.{ext}"
+    im.save(path, **kw)
+    got, ch, req = load(img, path)
+    want = {1: "L", 2: "LA", 4: "RGBA"}[req]
+    assert np.array_equal(got, np.asarray(Image.open(path).convert(want)).reshape(h, w, req))
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)
+
+
+def test_four_bit_bmp(img, oracle, tmp_path):
+    import struct
+    rng = np.random.default_rng(14)
+    w, h = 13, 5
+    idx = rng.integers(0, 16, size=(h, w), dtype=np.uint8)
+    pal = rng.integers(0, 256, size=(16, 3), dtype=np.uint8)
+    rows = b""
+    for y in range(h - 1, -1, -1):                  # bottom-up
+        packed = bytearray((w + 1) // 2)
+        for x in range(w):
+            packed[x >> 1] |= int(idx[y, x]) << (0 if x & 1 else 4)
+        rows += bytes(packed) + bytes((-len(packed)) % 4)
+    table = b"".join(bytes([int(b), int(g), int(r), 0]) for r, g, b in pal)
+    off = 14 + 40 + len(table)
+    data = b"BM" + struct.pack("<IHHI", off + len(rows), 0, 0, off) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 4, 0, len(rows), 0, 0, 16, 0) + table + rows
+    path = tmp_path / "n.bmp"
+    path.write_bytes(data)
+    got, ch, req = load(img, path)
+    assert (ch, req) == (3, 4) and np.array_equal(got[..., :3], pal[idx]) and (got[..., 3] == 255).all()
+    R = oracle.ref()
+    if R is not None:
+        ref, c, r = ref_load(R, path)
+        assert (c, r) == (ch, req) and np.array_equal(ref, got)
 
 
 @pytest.mark.parametrize("mode,size,kw", [("RGB", (43, 29), {"subsampling": 0}), ("RGB", (43, 29), {"subsampling": 1}),
