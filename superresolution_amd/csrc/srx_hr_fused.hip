@@ -112,9 +112,11 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         for (int r = 0; r < 16; ++r) bias[r] = src[(r & 3) + 8 * (r >> 2) + 4 * h];
     }
 
-    // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe; a static
-    // priority for every other workgroup keeps the two from settling into lockstep.  Workgroups b
-    // and b + #CUs usually share a CU; if they do not, nothing is lost.
+    // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe.  Workgroups b
+    // and b + #CUs share a CU; the second gets a higher wave priority.  Measured, that changes
+    // nothing (priority 0, 1 or 3: one workgroup of each pair gets about 65 % of the pipe and
+    // finishes first either way, and a pair made to advance evenly is slower in aggregate); it is
+    // kept so that which of the two runs ahead does not depend on arbitration details.
     if ((EXP & 2) == 0 && ((blockIdx.x / (gridDim.x >> 1 ? gridDim.x >> 1 : 1)) & 1)) __builtin_amdgcn_s_setprio(1);
 
     // never-written pad columns of the rings must hold finite values
