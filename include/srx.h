@@ -37,7 +37,10 @@ enum {
 /* srx_create flags */
 enum {
     /* Keep every layer's activations in HBM so srx_read_tensor() can return
-     * them (the debug taps used by the per-layer parity tests). */
+     * them (the debug taps used by the per-layer parity tests).  All tensors of
+     * the whole batch must fit the workspace limit (16 GB, or SRX_WORKSPACE_MB),
+     * about 1.2 KB per input pixel and frame; srx_create fails with
+     * SRX_ERR_NOMEM otherwise. */
     SRX_FLAG_KEEP_TENSORS = 1u << 0,
     /* Print "Number of weight tensors" / "Loaded tensor: ..." like
      * Content/LoadWeights.cpp:50,75 while parsing weights.bin. */
@@ -143,7 +146,10 @@ srx_status srx_sync(srx_ctx* ctx, void* stream);
 /* Debug tap: copy a kept tensor of one frame to host as planar CHW fp16
  * (the reference's effective layout, Content/SuperResolution.cpp:155-159);
  * fp32 with SRX_FLAG_FP32.  Needs SRX_FLAG_KEEP_TENSORS or a generic-layer
- * ctx.  `bytes` must be C*H*W*2 (*4 for fp32).  Synchronous. */
+ * ctx, with one exception: SRX_T_CONV_UP1, the only tensor the two fused
+ * kernels of the fast path pass through HBM, can be read from any ctx after
+ * srx_upscale / srx_process when batch <= srx_frames_per_launch().
+ * `bytes` must be C*H*W*2 (*4 for fp32).  Synchronous. */
 srx_status srx_read_tensor(srx_ctx* ctx, uint32_t frame, int32_t tensor_id,
                            void* fp16_chw_out, size_t bytes);
 srx_status srx_tensor_shape(const srx_ctx* ctx, int32_t tensor_id,
@@ -207,7 +213,8 @@ srx_status  srx_device_info(const srx_ctx* ctx, int32_t* compute_units, int32_t*
  *                     output buffer (pitch = out_w*4) and return it; the buffers of
  *                     a slot may be touched again only after this returned
  * A pipe is driven by one host thread; while it exists the ctx must not be
- * used through other entry points.
+ * used through other entry points, and srx_destroy of the ctx fails with
+ * SRX_ERR_STATE until the pipe has been destroyed.
  */
 typedef struct srx_pipe srx_pipe;
 srx_status srx_pipe_create(srx_ctx* ctx, uint32_t frames_per_slot, srx_pipe** out);

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -124,10 +125,14 @@ class SuperResolutionContext:
         _check(self._L.srx_create(C.byref(self._h), device, (weights_path or default_weights_path()).encode(),
                                   width, height, batch, flags))
         self.width, self.height, self.batch, self.flags = width, height, batch, flags
+        self._pipes = weakref.WeakSet()
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.srx_destroy(self._h)
+            # a pipe holds streams and pinned buffers that refer to this ctx: it goes first
+            for pipe in list(getattr(self, "_pipes", ())):
+                pipe.close()
+            _check(self._L.srx_destroy(self._h))
             self._h = None
 
     __del__ = close
@@ -231,6 +236,7 @@ class FramePipe:
         self.frames_per_slot = frames_per_slot
         self.slots = int(self._L.srx_pipe_slots(self._h))
         self.in_channels, self.out_channels = in_channels, out_channels
+        ctx._pipes.add(self)
         if (in_channels, out_channels) != (4, 4):
             _check(self._L.srx_pipe_set_channels(self._h, in_channels, out_channels))
 
@@ -238,6 +244,7 @@ class FramePipe:
         if getattr(self, "_h", None):
             self._L.srx_pipe_destroy(self._h)
             self._h = None
+            self._ctx._pipes.discard(self)
 
     __del__ = close
 
@@ -247,24 +254,34 @@ class FramePipe:
     def __exit__(self, *a):
         self.close()
 
+    def _view(self, ptr, nbytes):
+        # The array's base object refers to the pipe, so an array that is still referenced keeps the
+        # pipe (and its pinned memory) from being collected.  An explicit close() still frees the
+        # memory under any view: views are for use while the pipe is open.
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        buf._pipe = self
+        return np.frombuffer(buf, dtype=np.uint8)
+
     def input(self, slot):
-        """The slot's pinned input frames as a writable uint8 array [frames_per_slot, H, W, 4]."""
+        """The slot's pinned input frames as a writable uint8 array [frames_per_slot, H, W, channels]:
+        a view of pinned memory, valid until close()."""
         ptr, pitch, stride = C.c_void_p(), C.c_size_t(), C.c_size_t()
         _check(self._L.srx_pipe_input(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
-        n = self.frames_per_slot * stride.value
-        buf = (C.c_uint8 * n).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, self._ctx.height, self._ctx.width, self.in_channels)
+        return self._view(ptr.value, self.frames_per_slot * stride.value).reshape(
+            self.frames_per_slot, self._ctx.height, self._ctx.width, self.in_channels)
 
     def submit(self, slot):
         _check(self._L.srx_pipe_submit(self._h, slot))
 
-    def wait(self, slot):
-        """Block until the slot is done; returns its pinned output frames [frames_per_slot, 2H, 2W, 4] (a view)."""
+    def wait(self, slot, view=False):
+        """Block until the slot is done; returns its output frames [frames_per_slot, 2H, 2W, channels].
+        By default a copy, which outlives the pipe; view=True returns the pinned buffer itself, valid
+        until the slot is submitted again or the pipe is closed."""
         ptr, pitch, stride = C.c_void_p(), C.c_size_t(), C.c_size_t()
         _check(self._L.srx_pipe_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
-        n = self.frames_per_slot * stride.value
-        buf = (C.c_uint8 * n).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=np.uint8).reshape(self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, self.out_channels)
+        out = self._view(ptr.value, self.frames_per_slot * stride.value).reshape(
+            self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, self.out_channels)
+        return out if view else out.copy()
 
 
 def _sizes(v):

@@ -1,3 +1,5 @@
+// Adapted from StarsX/SuperResolution (SuperResolution/Common/DXFramework.cpp, whose file header reads "Copyright (c)
+// Microsoft. All rights reserved.  This code is licensed under the MIT License (MIT).").
 #include "DXFramework.h"
 
 #include <cstdio>

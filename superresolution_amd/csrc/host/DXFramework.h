@@ -1,3 +1,5 @@
+// Adapted from StarsX/SuperResolution (SuperResolution/Common/DXFramework.h, whose file header reads "Copyright (c)
+// Microsoft. All rights reserved.  This code is licensed under the MIT License (MIT)."): the framework base class, without the Win32 window.
 // Headless counterpart of the sample framework base class the reference's
 // SuperResolutionX derives from (Common/DXFramework.h:17-66): same virtual
 // interface and accessors, no window.  The "window title" is kept as a string

@@ -1,3 +1,6 @@
+// The LZW raster decoder below (Raster::emit / Raster::run) restates stbi__out_gif_code / stbi__process_gif_raster of
+// stb_image v2.30 (Sean Barrett and contributors; public domain / MIT No Attribution), so that GIFs decode to the bytes
+// the reference's loader gives.
 // GIF decoding (first image of the file) for the host program's image loader.
 //
 // The reference loads images through stb_image v2.30 (XUSG/Advanced/XUSGTextureLoader.h:17-32);

@@ -1,3 +1,6 @@
+// The inverse DCT (idct1d / idctBlock), the chroma upsampling and the colour conversion restate those of stb_image
+// v2.30 (Sean Barrett and contributors; public domain / MIT No Attribution; the DCT is the Independent JPEG Group's
+// jidctint), so that JPEGs decode to the bytes the reference's loader gives.
 // Baseline and progressive (Huffman, 8-bit) JPEG decoding for the host program's image loader.
 //
 // The reference loads images through stb_image v2.30 (XUSG/Advanced/XUSGTextureLoader.h:17-32),

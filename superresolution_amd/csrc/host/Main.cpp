@@ -3,59 +3,150 @@
 // ParseCommandLineArgs -> OnInit -> {OnUpdate, OnRender}* -> OnDestroy.
 //
 //   srx_main [-i|-image <png>] [-uma] [-warp]        the reference's switches
-//            [-frames N] [-update] [-o out.png] [-device D] [-noshot]
-// By default three frames are rendered with F11 "pressed" before the first one, so
+//            [-frames N] [-update] [-o out.png] [-device D] [-devices D0,D1,...] [-noshot]
+// By default five frames are rendered with F11 "pressed" before the first one, so
 // a SuperResolutionX_<timestamp>.png appears like the reference's screen shot.
+//
+// -devices lists the GPUs of a multi-GPU run (the reference picks ONE adapter,
+// SuperResolutionX.cpp:76-117; frames are independent, so here every listed device gets
+// its own SuperResolutionX on its own host thread and the frames {k, k + G, ...} of the
+// -frames N sequence, inference re-run for every frame, nothing exchanged between
+// devices).  A device may be listed more than once: its instances then share it.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "SuperResolutionX.h"
 
-int main(int argc, char* argv[])
+namespace {
+
+struct Options
 {
-    int frames = 5, device = 0;
+    int frames = 5;
     bool update = false, shot = true;
     std::string outPath;
-    std::vector<std::wstring> wide;
+    std::vector<std::wstring> wide;       // what the class's own ParseCommandLineArgs sees
+};
+
+// One instance on one device: the window loop's sequence for `frames` frames.
+void runInstance(const Options& opt, int device, int frames, bool update, bool shot, const std::string& outPath, bool quiet)
+{
+    std::vector<std::wstring> wide = opt.wide;
+    std::vector<wchar_t*> wargv;
+    for (auto& w : wide) wargv.push_back(&w[0]);
+
+    SuperResolutionX superResolutionX(1280, 720, L"Super resolution");
+    superResolutionX.ParseCommandLineArgs(wargv.data(), int(wargv.size()));
+    superResolutionX.SetDeviceIndex(device);
+    superResolutionX.OnInit();
+    if (!quiet) std::printf("output %ux%u\n", superResolutionX.GetWidth(), superResolutionX.GetHeight());
+    if (update) superResolutionX.OnKeyUp('U');
+    if (shot && outPath.empty()) superResolutionX.OnKeyUp(VK_F11);
+    for (int f = 0; f < frames; ++f)
+    {
+        superResolutionX.OnUpdate();
+        superResolutionX.OnRender();
+    }
+    if (!outPath.empty()) superResolutionX.SaveFrame(outPath.c_str());
+    superResolutionX.OnDestroy();
+}
+
+std::string indexedPath(const std::string& path, size_t k)
+{
+    const size_t dot = path.find_last_of('.');
+    const std::string tag = "." + std::to_string(k);
+    return dot == std::string::npos ? path + tag : path.substr(0, dot) + tag + path.substr(dot);
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    Options opt;
+    int device = 0;
+    std::vector<int> devices;
     for (int i = 0; i < argc; ++i)
     {
         const char* a = argv[i];
         const bool sw = i > 0 && (a[0] == '-' || a[0] == '/');
-        if (sw && !strcasecmp(a + 1, "frames") && i + 1 < argc) { frames = std::atoi(argv[++i]); continue; }
+        if (sw && !strcasecmp(a + 1, "frames") && i + 1 < argc) { opt.frames = std::atoi(argv[++i]); continue; }
         if (sw && !strcasecmp(a + 1, "device") && i + 1 < argc) { device = std::atoi(argv[++i]); continue; }
-        if (sw && !strcasecmp(a + 1, "o") && i + 1 < argc) { outPath = argv[++i]; continue; }
-        if (sw && !strcasecmp(a + 1, "update")) { update = true; continue; }
-        if (sw && !strcasecmp(a + 1, "noshot")) { shot = false; continue; }
-        wide.emplace_back(a, a + std::strlen(a));
-    }
-    std::vector<wchar_t*> wargv;
-    for (auto& w : wide) wargv.push_back(&w[0]);
-
-    try
-    {
-        SuperResolutionX superResolutionX(1280, 720, L"Super resolution");
-        superResolutionX.ParseCommandLineArgs(wargv.data(), int(wargv.size()));
-        superResolutionX.SetDeviceIndex(device);
-        superResolutionX.OnInit();
-        std::printf("output %ux%u\n", superResolutionX.GetWidth(), superResolutionX.GetHeight());
-        if (update) superResolutionX.OnKeyUp('U');
-        if (shot && outPath.empty()) superResolutionX.OnKeyUp(VK_F11);
-        for (int f = 0; f < frames; ++f)
+        if (sw && !strcasecmp(a + 1, "devices") && i + 1 < argc)
         {
-            superResolutionX.OnUpdate();
-            superResolutionX.OnRender();
+            for (const char* p = argv[++i]; *p;)
+            {
+                char* end = nullptr;
+                const long d = std::strtol(p, &end, 10);
+                if (end == p || d < 0) { std::fprintf(stderr, "error: -devices expects a comma-separated list of device indices\n"); return 1; }
+                devices.push_back(int(d));
+                p = *end == ',' ? end + 1 : end;
+            }
+            continue;
         }
-        if (!outPath.empty()) superResolutionX.SaveFrame(outPath.c_str());
-        superResolutionX.OnDestroy();
+        if (sw && !strcasecmp(a + 1, "o") && i + 1 < argc) { opt.outPath = argv[++i]; continue; }
+        if (sw && !strcasecmp(a + 1, "update")) { opt.update = true; continue; }
+        if (sw && !strcasecmp(a + 1, "noshot")) { opt.shot = false; continue; }
+        opt.wide.emplace_back(a, a + std::strlen(a));
     }
-    catch (const std::exception& e)
+
+    if (devices.empty())
     {
-        std::fprintf(stderr, "error: %s\n", e.what());
-        return 1;
+        try
+        {
+            runInstance(opt, device, opt.frames, opt.update, opt.shot, opt.outPath, false);
+        }
+        catch (const std::exception& e)
+        {
+            std::fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+        return 0;
     }
-    return 0;
+
+    // Frame-sharded run: instance k takes frames k, k + G, ...
+    const size_t G = devices.size();
+    std::vector<std::string> errors(G);
+    std::vector<double> seconds(G, 0.0);
+    std::vector<int> share(G, 0);
+    std::vector<std::thread> threads;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < G; ++k)
+    {
+        share[k] = (opt.frames > int(k)) ? (opt.frames - int(k) + int(G) - 1) / int(G) : 0;
+        threads.emplace_back([&, k] {
+            try
+            {
+                const auto s0 = std::chrono::steady_clock::now();
+                const std::string out = opt.outPath.empty() ? std::string() : indexedPath(opt.outPath, k);
+                runInstance(opt, devices[k], share[k], true, false, out, k != 0);
+                seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+            }
+            catch (const std::exception& e)
+            {
+                errors[k] = e.what();
+            }
+        });
+    }
+    for (auto& t : threads) t.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int rc = 0, done = 0;
+    for (size_t k = 0; k < G; ++k)
+    {
+        if (!errors[k].empty())
+        {
+            std::fprintf(stderr, "error: instance %zu (device %d): %s\n", k, devices[k], errors[k].c_str());
+            rc = 1;
+            continue;
+        }
+        done += share[k];
+        std::printf("instance %zu on device %d: %d frames in %.3f s (start-up included)\n", k, devices[k], share[k], seconds[k]);
+    }
+    std::printf("%d frames on %zu instances in %.3f s\n", done, G, wall);
+    return rc;
 }

@@ -1,3 +1,7 @@
+// Adapted from StarsX/SuperResolution (SuperResolution/SuperResolutionX.cpp), whose file header reads
+// "Copyright (c) Microsoft. All rights reserved.  This code is licensed under the MIT License (MIT).":
+// OnKeyUp, the command-line switches, the screen-shot sequence and the frame statistics follow the reference so that
+// the class stays a drop-in; device, queue, swap chain and fences are replaced by a HIP device index and one stream.
 #include "SuperResolutionX.h"
 
 #include <cwchar>

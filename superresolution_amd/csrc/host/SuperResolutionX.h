@@ -1,3 +1,6 @@
+// Adapted from StarsX/SuperResolution (SuperResolution/SuperResolutionX.h), whose file header reads
+// "Copyright (c) Microsoft. All rights reserved.  This code is licensed under the MIT License (MIT).":
+// the public interface and the member names are the reference's.
 // The application class of the sample, headless.  Public interface as in the
 // reference (SuperResolutionX.h:26-39): constructor (width, height, name) and the
 // DXFramework overrides OnInit / OnUpdate / OnRender / OnDestroy / OnKeyUp /

@@ -96,6 +96,7 @@ struct srx_ctx
 
     std::vector<void*> allocs;
     std::vector<uint8_t> hostStage;
+    int livePipes = 0;                       // frame pipes created on this ctx and not yet destroyed
 
     // the graph made of generic layers (SRX_FLAG_GENERIC_LAYERS / FP32 / NHWC)
     struct Generic
@@ -222,6 +223,7 @@ srx_status allocTensors(srx_ctx* c)
     perFrame = std::max<size_t>(perFrame, 1);
     const uint32_t maxChunk = uint32_t(std::max<size_t>(1, std::min<size_t>(c->batch, limit / perFrame)));
     uint32_t chunk = uint32_t(std::max<size_t>(1, std::min<size_t>(maxChunk, (size_t(256) << 20) / perFrame)));
+    if (c->keep()) chunk = maxChunk;         // every kept tensor of the whole batch must be resident: only the workspace limit applies
     if (!c->keep())
     {
         // cost of one pass of n frames, and of the whole batch in passes of n (the last pass takes the rest)
@@ -244,7 +246,8 @@ srx_status allocTensors(srx_ctx* c)
         }
     }
     if (c->keep() && chunk < c->batch)
-        return fail(SRX_ERR_NOMEM, "SRX_FLAG_KEEP_TENSORS needs the whole batch resident; reduce batch");
+        return fail(SRX_ERR_NOMEM, "SRX_FLAG_KEEP_TENSORS needs every tensor of the whole batch resident, which exceeds the "
+                                   "workspace limit (16 GB, or SRX_WORKSPACE_MB): reduce batch or raise the limit");
     c->chunk = chunk;
 
     for (int id = 0; id < SRX_T_COUNT; ++id)
@@ -436,10 +439,10 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
     if (!out) return fail(SRX_ERR_INVALID, "srx_create: out is NULL");
     *out = nullptr;
     if (!weights_path) return fail(SRX_ERR_INVALID, "srx_create: weights_path is NULL");
-    // one output frame (2W x 2H x 4 bytes) must stay addressable with a 32-bit offset
+    // one output frame (2W x 2H x 4 bytes) must stay addressable with a signed 32-bit byte offset
     if (in_w == 0 || in_h == 0 || batch == 0 || in_w > 16384 || in_h > 16384 ||
-        uint64_t(in_w) * in_h > (uint64_t(1) << 27))
-        return fail(SRX_ERR_INVALID, "srx_create: image size must be 1..16384 per side, at most 2^27 pixels, and batch >= 1");
+        uint64_t(in_w) * in_h * 16 >= (uint64_t(1) << 31))
+        return fail(SRX_ERR_INVALID, "srx_create: image size must be 1..16384 per side, fewer than 2^27 pixels, and batch >= 1");
 
     srx::ML::WeightMapType weights;
     if (!srx::LoadWeights(weights_path, weights, (flags & SRX_FLAG_VERBOSE_WEIGHTS) != 0))
@@ -507,6 +510,8 @@ SRX_CATCH
 srx_status srx_destroy(srx_ctx* c) try
 {
     if (!c) return SRX_OK;
+    if (c->livePipes > 0)
+        return fail(SRX_ERR_STATE, "srx_destroy: a frame pipe of this ctx is still alive; call srx_pipe_destroy first");
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();          // no buffer is freed while stream work is pending
     for (void* p : c->allocs) (void)hipFree(p);
@@ -684,7 +689,13 @@ srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, si
 {
     if (!validCtx(c) || id < 0 || id >= SRX_T_COUNT || frame >= c->batch || !out)
         return fail(SRX_ERR_INVALID, "srx_read_tensor: bad argument");
-    if (!c->keep() && !c->generic()) return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create");
+    // The two fused kernels keep every tensor but conv_up1's output on the chip.  That one is in HBM, and
+    // after srx_upscale / srx_process it still holds every frame when one pass covers the whole batch.
+    if (!c->keep() && !c->generic() && id != SRX_T_CONV_UP1)
+        return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create (without it only SRX_T_CONV_UP1 reaches HBM)");
+    if (!c->keep() && !c->generic() && c->chunk < c->batch)
+        return fail(SRX_ERR_STATE, "srx_read_tensor(SRX_T_CONV_UP1): the batch runs in several passes that share one workspace; "
+                                   "use a batch of at most srx_frames_per_launch() frames");
     const TensorInfo& ti = kTensorInfo[id];
     const size_t H = size_t(c->height) * ti.scale, W = size_t(c->width) * ti.scale;
     if (c->generic())
@@ -915,6 +926,8 @@ SRX_CATCH
 struct srx_pipe
 {
     srx_ctx* ctx = nullptr;
+    int device = 0;                          // the ctx's device, kept here so that destruction never reads the ctx's fields
+    bool counted = false;                    // this pipe is included in ctx->livePipes
     uint32_t perSlot = 0, slots = 0;
     size_t inPitch = 0, inFrame = 0, outPitch = 0, outFrame = 0;    // host layouts (tightly packed)
     std::vector<uint8_t*> hostIn, hostOut;
@@ -928,9 +941,10 @@ struct srx_pipe
 srx_status srx_pipe_destroy(srx_pipe* p) try
 {
     if (!p) return SRX_OK;
-    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    (void)hipSetDevice(p->device);
     for (hipStream_t st : {p->up, p->comp, p->down})
         if (st) (void)hipStreamSynchronize(st);
+    if (p->counted && p->ctx) --p->ctx->livePipes;
     for (uint8_t* h : p->hostIn) if (h) (void)hipHostFree(h);
     for (uint8_t* h : p->hostOut) if (h) (void)hipHostFree(h);
     for (uint8_t* d : p->devRgbIn) if (d) (void)hipFree(d);
@@ -956,6 +970,7 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
     std::unique_ptr<srx_pipe, Destroy> owner(new srx_pipe);    // released on success only
     srx_pipe* p = owner.get();
     p->ctx = c;
+    p->device = c->device;
     p->perSlot = framesPerSlot;
     p->slots = c->batch / framesPerSlot;
     p->inPitch = size_t(c->width) * 4;
@@ -984,6 +999,8 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
         for (hipEvent_t* ev : {&p->evUp[s], &p->evComp[s], &p->evDown[s]})
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreateWithFlags");
     }
+    ++c->livePipes;
+    p->counted = true;
     *out = owner.release();
     return SRX_OK;
 }
@@ -1094,7 +1111,7 @@ srx_status srx_pipe_wait(srx_pipe* p, uint32_t slot, const uint8_t** host, size_
 {
     if (!p || slot >= p->slots) return fail(SRX_ERR_INVALID, "srx_pipe_wait: bad pipe or slot");
     if (!p->submitted[slot]) return fail(SRX_ERR_STATE, "srx_pipe_wait: the slot was never submitted");
-    SRX_HIP(hipSetDevice(p->ctx->device));
+    SRX_HIP(hipSetDevice(p->device));
     SRX_HIP(hipEventSynchronize(p->evDown[slot]));
     if (host) *host = p->hostOut[slot];
     if (pitch) *pitch = p->outPitch;

@@ -79,14 +79,22 @@ __device__ __forceinline__ void barrierLds()
 
 // Diagnostic: when the environment variable SRX_CLOCK is set, a kernel's workgroups record how many
 // shader cycles and how many 100-MHz reference ticks they ran for, and the launcher prints the
-// resulting in-kernel clock after a number of launches.  The buffer is read by no kernel.
+// resulting in-kernel clock after a number of launches.  The buffer is read by no kernel.  There is
+// one probe per (device, kernel): the table behind clockProbeFor is guarded by a mutex, so launches
+// from several host threads (one per GPU) do not share a buffer or race on the counters.
 struct ClockProbe
 {
-    unsigned long long* dev = nullptr;   // [2 * maxBlocks], or nullptr when the probe is off
+    unsigned long long* dev = nullptr;   // [2 * maxBlocks] on the probe's device, or nullptr when the probe is off
     int launches = 0;
 };
-unsigned long long* clockProbeBuffer(ClockProbe& probe, int blocks);
-void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream_t s);
+enum ProbedKernel { PROBE_LR_FUSED = 0, PROBE_HR_FUSED = 1, PROBE_COUNT };
+// The probe of `kernel` on the current device, with its buffer allocated; nullptr when SRX_CLOCK is unset,
+// when `blocks` exceeds the buffer, or when `mayAllocate` is false and the buffer does not exist yet.
+ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate);
+void clockProbeReport(ClockProbe* probe, const char* name, int blocks, hipStream_t s);
+
+// Raise a kernel's dynamic shared memory limit, once per (device, kernel).  Thread-safe.
+hipError_t ensureDynamicLds(const void* kernel, int bytes);
 
 inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }
 

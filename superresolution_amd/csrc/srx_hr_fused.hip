@@ -414,23 +414,15 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     const char* env = getenv("SRX_EXP");
     const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs)), block(kThreads);
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
 #define SRX_HR_CASE(E)                                                                                       \
     case E: {                                                                                                \
-        static bool attr[64] = {};                                                                           \
-        if (!attr[device])                                                                                   \
-        {                                                                                                    \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(HrFusedKernel<E>),        \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kHrSmem);   \
-            if (e != hipSuccess) return e;                                                                   \
-            attr[device] = true;                                                                             \
-        }                                                                                                    \
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<E>), kHrSmem);     \
+        if (e != hipSuccess) return e;                                                                       \
         hipLaunchKernelGGL(HrFusedKernel<E>, grid, block, kHrSmem, s, p);                                    \
         break;                                                                                               \
     }
-    static ClockProbe probe;
-    p.clock = clockProbeBuffer(probe, int(grid.x));
+    ClockProbe* const probe = clockProbeFor(PROBE_HR_FUSED, int(grid.x), l.mayAllocate);
+    p.clock = probe ? probe->dev : nullptr;
     switch (exp)
     {
         SRX_HR_CASE(1) SRX_HR_CASE(2)

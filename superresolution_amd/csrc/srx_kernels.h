@@ -66,6 +66,7 @@ struct HrFusedLaunch
     Image image;
     int width2 = 0, height2 = 0;     // size of the 2x grid
     int batch = 1;
+    bool mayAllocate = true;         // false: the launch must not allocate (no diagnostic probe buffer is created)
 };
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s);
 
@@ -80,6 +81,7 @@ struct LrFusedLaunch
     const float* bias = nullptr;     // conv_up1[32] | conv3[64] | conv2[64] | conv1[32], fp32
     int width = 0, height = 0;       // input size
     int batch = 1;
+    bool mayAllocate = true;         // false: the launch must not allocate (no diagnostic probe buffer is created)
 };
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 

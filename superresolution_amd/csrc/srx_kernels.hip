@@ -20,6 +20,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace srx {
@@ -320,20 +323,56 @@ hipError_t launch3x3(const ConvParams& p, int numCUs, hipStream_t s)
 
 namespace dev {
 
-unsigned long long* clockProbeBuffer(ClockProbe& probe, int blocks)
-{
-    static const bool on = getenv("SRX_CLOCK") != nullptr;
-    if (!on || blocks > 4096) return nullptr;
-    if (!probe.dev && hipMalloc(&probe.dev, 2 * 4096 * sizeof(unsigned long long)) != hipSuccess) probe.dev = nullptr;
-    return probe.dev;
+namespace {
+std::mutex g_launchStateMutex;
+constexpr int kMaxDevices = 64, kProbeBlocks = 4096;
 }
 
-void clockProbeReport(ClockProbe& probe, const char* name, int blocks, hipStream_t s)
+ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate)
 {
-    if (!probe.dev || ++probe.launches != 40) return;
+    static const bool on = getenv("SRX_CLOCK") != nullptr;
+    if (!on || blocks > kProbeBlocks) return nullptr;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
+    static ClockProbe probes[kMaxDevices][PROBE_COUNT];
+    std::lock_guard<std::mutex> lock(g_launchStateMutex);
+    ClockProbe& probe = probes[device][kernel];
+    if (!probe.dev)
+    {
+        if (!mayAllocate) return nullptr;
+        if (hipMalloc(&probe.dev, 2 * kProbeBlocks * sizeof(unsigned long long)) != hipSuccess)
+        {
+            probe.dev = nullptr;
+            return nullptr;
+        }
+    }
+    return &probe;
+}
+
+hipError_t ensureDynamicLds(const void* kernel, int bytes)
+{
+    int device = 0;
+    const hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    static std::set<std::pair<int, const void*>> done;
+    std::lock_guard<std::mutex> lock(g_launchStateMutex);
+    if (done.count({device, kernel})) return hipSuccess;
+    const hipError_t r = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (r == hipSuccess) done.insert({device, kernel});
+    return r;
+}
+
+void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStream_t s)
+{
+    if (!probePtr) return;
+    ClockProbe& probe = *probePtr;
+    {
+        std::lock_guard<std::mutex> lock(g_launchStateMutex);
+        if (++probe.launches != 40) return;
+    }
     if (hipStreamSynchronize(s) != hipSuccess) return;
-    static unsigned long long host[2 * 4096];
-    if (hipMemcpy(host, probe.dev, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::vector<unsigned long long> host(2 * size_t(blocks));
+    if (hipMemcpy(host.data(), probe.dev, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
     double sum = 0, cyc = 0, usMin = 1e30, usMax = 0, usSum = 0, ghzMin = 1e30, ghzMax = 0;
     double xcdUs[8] = {};
     for (int b = 0; b < blocks; ++b)

@@ -415,18 +415,10 @@ hipError_t DispatchOperator(const ML::Operator& op, const void* input, const voi
         {
             // fp16 tensors run on the matrix cores (SRX_GENERIC_VALU keeps the direct kernel, for comparison)
             const int lds = convMfmaLdsBytes(a.kh, a.kw);
-            int device = 0;
-            if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
-            static bool attr[64] = {};
-            if (!attr[device])
-            {
-                const int most = convMfmaLdsBytes(kKMax, kKMax);
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ConvMfmaKernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-                if (e == hipSuccess)
-                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ConvMfmaKernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-                if (e != hipSuccess) return e;
-                attr[device] = true;
-            }
+            const int most = convMfmaLdsBytes(kKMax, kKMax);
+            hipError_t e = dev::ensureDynamicLds(reinterpret_cast<const void*>(ConvMfmaKernel<true>), most);
+            if (e == hipSuccess) e = dev::ensureDynamicLds(reinterpret_cast<const void*>(ConvMfmaKernel<false>), most);
+            if (e != hipSuccess) return e;
             const dim3 mgrid(a.tilesX * a.tilesY, (a.O + kMO - 1) / kMO, a.N);
             if (nhwc) hipLaunchKernelGGL((ConvMfmaKernel<true>), mgrid, block, lds, s, a);
             else hipLaunchKernelGGL((ConvMfmaKernel<false>), mgrid, block, lds, s, a);

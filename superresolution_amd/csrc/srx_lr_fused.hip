@@ -624,20 +624,12 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     const char* env = getenv("SRX_EXP_LR");
     const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return hipErrorInvalidDevice;
-    static ClockProbe probe;
-    p.clock = clockProbeBuffer(probe, int(grid.x));
+    ClockProbe* const probe = clockProbeFor(PROBE_LR_FUSED, int(grid.x), l.mayAllocate);
+    p.clock = probe ? probe->dev : nullptr;
 #define SRX_LR_CASE(E)                                                                                       \
     case E: {                                                                                                \
-        static bool attr[64] = {};                                                                           \
-        if (!attr[device])                                                                                   \
-        {                                                                                                    \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(LrFusedKernel<E>),        \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLrSmem);   \
-            if (e != hipSuccess) return e;                                                                   \
-            attr[device] = true;                                                                             \
-        }                                                                                                    \
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<E>), kLrSmem);     \
+        if (e != hipSuccess) return e;                                                                       \
         hipLaunchKernelGGL(LrFusedKernel<E>, grid, block, kLrSmem, s, p);                                    \
         break;                                                                                               \
     }

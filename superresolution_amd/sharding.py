@@ -119,3 +119,16 @@ def max_over_ranks(seconds):
     t = torch.tensor([seconds], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value):
+    """Every rank's `value` (a float), in rank order, on every rank; [value] without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]

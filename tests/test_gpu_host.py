@@ -104,3 +104,20 @@ def test_other_input_formats(workdir, ext, kw):
     with S.SuperResolutionContext(128, 128) as ctx:
         want = ctx.run(rgba)
     assert np.array_equal(np.asarray(Image.open(workdir / "o.png")), want[..., :3])
+
+
+def test_devices_switch_shards_frames_over_instances(workdir):
+    """-devices: one SuperResolutionX per listed device on its own host thread, frames dealt round-robin.
+    On a one-GPU box the device is listed twice, so two instances (two ctxs, two streams, two threads)
+    share it; both must produce the picture of a plain run."""
+    r = run(["-i", "Assets/Sashimi.png", "-o", "one.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    r = run(["-i", "Assets/Sashimi.png", "-devices", "0,0", "-frames", "7", "-o", "multi.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "instance 0 on device 0: 4 frames" in r.stdout and "instance 1 on device 0: 3 frames" in r.stdout
+    assert "7 frames on 2 instances" in r.stdout
+    want = np.asarray(Image.open(workdir / "one.png"))
+    for k in range(2):
+        assert np.array_equal(np.asarray(Image.open(workdir / f"multi.{k}.png")), want)
+    r = run(["-devices", "0,99", "-frames", "2"], workdir)
+    assert r.returncode != 0 and "device index out of range" in r.stderr

@@ -230,3 +230,51 @@ def test_layer_factories_reproduce_the_reference_buffer_plan():
         S.layer_plan(1, 0, (1, 3, 8, 8), (0, 2, 0, 0))
     with pytest.raises(S.SrxError):
         S.layer_plan(7, 0, (1, 3, 8, 8), (1, 1, 1, 1))
+
+
+def test_create_rejects_sizes_before_touching_a_device():
+    """Size validation is host-only: 2^27 input pixels would make one output frame exactly 2^31 bytes, which
+    the kernels' 32-bit byte offsets cannot address."""
+    L = S.lib()
+    h = C.c_void_p()
+    wp = S.default_weights_path().encode()
+    for w, hh, batch in [(16384, 8192, 1), (8192, 16384, 1), (16385, 16, 1), (16, 16385, 1), (0, 16, 1), (16, 0, 1), (16, 16, 0)]:
+        assert L.srx_create(C.byref(h), 0, wp, w, hh, batch, 0) == 1, (w, hh, batch)
+        assert not h.value
+        assert b"fewer than 2^27 pixels" in L.srx_last_error()
+
+
+def test_up1_phase_form_with_all_channels():
+    """The four-phase form of conv_up1 with the library's own phase filters (unpacked from the fragments the
+    kernels load), all 64 x 32 channels, borders included.  With exact (float64, unrounded) tap sums it IS the
+    reference's direct 5x5 convolution of the nearest-neighbour-upsampled tensor; the fp16 rounding of the summed
+    taps is the only difference of the product path, and its size is stated here."""
+    f, b = S.fold_weights(3)
+    w = f.view(np.float16).astype(np.float64).reshape(32, 64, 5, 5)
+    groups = {0: [[0, 1], [2, 3], [4]], 1: [[0], [1, 2], [3, 4]]}
+    rng = np.random.default_rng(3)
+    # activations like conv3's output: non-negative, fp16, sparse, magnitudes of a few units
+    x = np.maximum(rng.standard_normal((64, 9, 11)) * 1.5, 0).astype(np.float16).astype(np.float64)
+    up = np.pad(np.repeat(np.repeat(x, 2, 1), 2, 2), ((0, 0), (2, 2), (2, 2)))
+    direct = np.zeros((32, 18, 22))
+    for i in range(5):
+        for j in range(5):
+            direct += np.einsum("oc,chw->ohw", w[:, :, i, j], up[:, i:i + 18, j:j + 22])
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1)))
+    packed = S.packed_weights(3).reshape(4, -1)
+    exact, rounded = np.zeros_like(direct), np.zeros_like(direct)
+    for py in range(2):
+        for px in range(2):
+            lib = _unpack3x3(packed[py * 2 + px], 32, 64).view(np.float16).astype(np.float64).reshape(32, 64, 3, 3)
+            for a, rows in enumerate(groups[py]):
+                for c, cols in enumerate(groups[px]):
+                    tap = w[:, :, rows][:, :, :, cols].sum(axis=(2, 3))
+                    win = xp[:, a:a + 9, c:c + 11]
+                    exact[:, py::2, px::2] += np.einsum("oc,chw->ohw", tap, win)
+                    rounded[:, py::2, px::2] += np.einsum("oc,chw->ohw", lib[:, :, a, c], win)
+    assert np.abs(exact - direct).max() < 1e-9
+    err = np.abs(rounded - direct).max()
+    # measured: 1.5e-3 for results of magnitude up to 5.6, i.e. under one fp16 ulp (3.9e-3) of such a result
+    # and under a tenth of the 2e-2 the path is specified to
+    assert err < 3e-3, err
+    assert np.abs(direct).max() > 4
