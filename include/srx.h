@@ -140,6 +140,31 @@ srx_status srx_upscale(srx_ctx* ctx, void* stream);
  * on ONE compute stream).  Not available with SRX_FLAG_KEEP_TENSORS. */
 srx_status srx_upscale_frames(srx_ctx* ctx, uint32_t first, uint32_t count, void* stream);
 
+/*
+ * The same upscale for callers that must not allocate.  It has no counterpart in the
+ * reference: it exists for code under HIP graph capture, tight serving loops and
+ * harnesses that forbid hipMalloc.  One w x h RGBA8 image in device memory at `in`
+ * (rows in_pitch bytes apart) is upscaled into the 2w x 2h RGBA8 image at `out`
+ * (rows out_pitch bytes apart) with the ctx's weights, by the same two fused kernels
+ * srx_upscale launches; the caller owns both images.  The one tensor those kernels
+ * pass through device memory lives in a workspace that is part of the library's
+ * device image, SRX_STATIC_SCRATCH_BYTES on every GPU the library runs on, held until
+ * the process ends; the call performs no hipMalloc / hipFree and no other allocation
+ * (its set-up was done by srx_create of `ctx`).  The ctx's own size and batch do not
+ * matter; pointers and pitches must be multiples of 4.  Images whose workspace need,
+ * 64 bytes per OUTPUT pixel plus borders, exceeds the static workspace are refused
+ * with SRX_ERR_INVALID (640x360 fits, 1280x720 does not): use srx_upscale for those.
+ * All calls on one GPU share that GPU's workspace: calls that overlap in time on one
+ * GPU, from any ctx, thread or stream, race on it -- order them on one stream.
+ * Asynchronous on `stream`.
+ */
+#define SRX_STATIC_SCRATCH_BYTES (64u << 20)
+srx_status srx_upscale_static(srx_ctx* ctx, const void* in_rgba8, size_t in_pitch,
+                              void* out_rgba8, size_t out_pitch,
+                              uint32_t in_w, uint32_t in_h, void* stream);
+/* SRX_STATIC_SCRATCH_BYTES of the loaded library. */
+size_t srx_static_scratch_bytes(void);
+
 /* WaitForGpu (SuperResolutionX.cpp:374-385). */
 srx_status srx_sync(srx_ctx* ctx, void* stream);
 

@@ -22,7 +22,8 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_device_info", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan"]
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan",
+           "srx_upscale_static", "srx_static_scratch_bytes"]
 
 
 class SrxError(RuntimeError):
@@ -90,6 +91,8 @@ def lib():
     L.srx_frames_per_launch.argtypes = [vp]
     L.srx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
     L.srx_upscale_frames.argtypes = [vp, u32, u32, vp]
+    L.srx_upscale_static.argtypes = [vp, vp, sz, vp, sz, u32, u32, vp]
+    L.srx_static_scratch_bytes.argtypes = []
     L.srx_pipe_create.argtypes = [vp, u32, C.POINTER(vp)]
     L.srx_pipe_destroy.argtypes = [vp]
     L.srx_pipe_slots.argtypes = [vp]
@@ -103,9 +106,10 @@ def lib():
     L.srx_layer_add.argtypes = [i32, vp, vp, vp, sz, vp]
     L.srx_layer_plan.argtypes = [i32, i32, u32x4, u32x4, u32x4, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     for name in SYMBOLS:
-        if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch", "srx_pipe_slots"):
+        if name not in ("srx_stage_name", "srx_last_error", "srx_frames_per_launch", "srx_pipe_slots", "srx_static_scratch_bytes"):
             getattr(L, name).restype = i32
     L.srx_frames_per_launch.restype = u32
+    L.srx_static_scratch_bytes.restype = sz
     L.srx_pipe_slots.restype = u32
     _lib = L
     return L
@@ -184,6 +188,10 @@ class SuperResolutionContext:
 
     def sync(self, stream=None):
         _check(self._L.srx_sync(self._h, stream))
+
+    def upscale_static(self, in_ptr, in_pitch, out_ptr, out_pitch, width, height, stream=None):
+        """srx_upscale_static on caller-owned device images (addresses as integers): allocates nothing."""
+        _check(self._L.srx_upscale_static(self._h, in_ptr, in_pitch, out_ptr, out_pitch, width, height, stream))
 
     def tensor_to_image(self, frame=0, stream=None):
         w, h = self.out_size

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -70,6 +71,50 @@ const char* const kStageNames[] = {"image_to_tensor", "conv1", "conv2", "conv3",
                                    "conv4", "conv5", "conv6_add_unorm", "conv4_conv5_conv6_add_unorm",
                                    "pack_conv1_conv2_conv3_conv_up1", "generic_layer_graph"};
 
+// Workspace of srx_upscale_static: conv_up1's output (the one tensor the two fused kernels pass through
+// device memory) for one image.  Every GPU the library runs on holds its own copy of this array until the
+// process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: what kernels and
+// memsets get is the per-device address kept in g_staticScratch.
+constexpr size_t kStaticScratchBytes = size_t(SRX_STATIC_SCRATCH_BYTES);
+constexpr int kMaxDevices = 64;
+std::mutex g_staticScratchMutex;
+void* g_staticScratch[kMaxDevices] = {};
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+
+// Address of `scratch` on `device` (which must be the current device); looked up once per device.
+srx_status staticScratchFor(int device, void** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(SRX_ERR_INVALID, "device index must be below 64");
+    std::lock_guard<std::mutex> lock(g_staticScratchMutex);
+    if (!g_staticScratch[device])
+    {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(SRX_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_staticScratch[device] = ptr;
+    }
+    *out = g_staticScratch[device];
+    return SRX_OK;
+}
+
+// Layout of conv_up1's output for one w x h input frame, as both fused kernels address it.
+struct Up1Layout { int pitch, rows; size_t bytes; };
+Up1Layout up1Layout(uint32_t w, uint32_t h)
+{
+    const TensorInfo& ti = kTensorInfo[SRX_T_CONV_UP1];
+    Up1Layout l;
+    l.pitch = roundUp(int(w) * ti.scale, srx::kTileW) + 2 * ti.border + ti.slackRight;
+    l.rows = roundUp(int(h) * ti.scale, srx::kTileH) + 2 * ti.border;
+    l.bytes = size_t(l.pitch) * l.rows * ti.storedChannels * 2;
+    return l;
+}
+
 }  // namespace
 
 struct srx_ctx
@@ -96,6 +141,7 @@ struct srx_ctx
 
     std::vector<void*> allocs;
     std::vector<uint8_t> hostStage;
+    void* staticScratch = nullptr;           // this device's copy of `scratch` (srx_upscale_static)
     int livePipes = 0;                       // frame pipes created on this ctx and not yet destroyed
 
     // the graph made of generic layers (SRX_FLAG_GENERIC_LAYERS / FP32 / NHWC)
@@ -472,6 +518,13 @@ srx_status srx_create(srx_ctx** out, int device, const char* weights_path,
             return bail(fail(SRX_ERR_HIP, std::string("this library is built for gfx950 only; device is ") + prop.gcnArchName));
         c->numCUs = prop.multiProcessorCount;
     }
+    // set-up for srx_upscale_static: this device's address of the static workspace, and the fused kernels
+    // loaded on this device with their shared-memory limit raised, so that the entry point itself does neither
+    if (const srx_status s = staticScratchFor(device, &c->staticScratch)) return bail(s);
+    {
+        const hipError_t e = srx::PrepareFusedKernels();
+        if (e != hipSuccess) return bail(fail(SRX_ERR_HIP, std::string("PrepareFusedKernels: ") + hipGetErrorString(e)));
+    }
 
     c->input.pitch = int64_t(in_w) * 4;
     c->input.frame = c->input.pitch * in_h;
@@ -648,6 +701,79 @@ srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* 
     return SRX_OK;
 }
 SRX_CATCH
+
+srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* out, size_t outPitch,
+                              uint32_t w, uint32_t h, void* stream) try
+{
+    if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");
+    if (c->generic()) return fail(SRX_ERR_STATE, "srx_upscale_static: not available on a generic-layer ctx (it holds no fused-kernel weights)");
+    if (!in || !out || w == 0 || h == 0 || w > 16384 || h > 16384)
+        return fail(SRX_ERR_INVALID, "srx_upscale_static: NULL image or a side outside 1..16384");
+    if (inPitch < size_t(w) * 4 || outPitch < size_t(w) * 8 || (inPitch & 3) || (outPitch & 3) ||
+        (reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3))
+        return fail(SRX_ERR_INVALID, "srx_upscale_static: pitches must cover a row (4 bytes per pixel) and, like the pointers, be multiples of 4");
+    const Up1Layout lay = up1Layout(w, h);
+    if (lay.bytes > kStaticScratchBytes)
+        return fail(SRX_ERR_INVALID, "srx_upscale_static: image too large for the static workspace: 64 bytes per output pixel plus borders "
+                                     "must fit " + std::to_string(kStaticScratchBytes >> 20) + " MiB (e.g. 640x360 fits, 1280x720 does not); "
+                                     "use srx_upscale for larger images");
+    if (inPitch * h >= (size_t(1) << 31) || outPitch * h * 2 >= (size_t(1) << 31))
+        return fail(SRX_ERR_INVALID, "srx_upscale_static: an image must span fewer than 2^31 bytes");
+    SRX_HIP(hipSetDevice(c->device));
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+
+    // The workspace keeps what the previous call left.  Its border, the padding to whole tiles and the slack
+    // to the right must read as zeros (they are the zero padding of conv4), and their position depends on
+    // the image size: clear the part this call uses.
+    SRX_HIP(hipMemsetAsync(c->staticScratch, 0, lay.bytes, st));
+
+    const TensorInfo& ti = kTensorInfo[SRX_T_CONV_UP1];
+    srx::Tensor a4;
+    a4.channels = ti.storedChannels;
+    a4.pitch = lay.pitch;
+    a4.frame = int64_t(lay.pitch) * lay.rows * ti.storedChannels;
+    a4.base = static_cast<uint16_t*>(c->staticScratch) + (size_t(ti.border) * lay.pitch + ti.border) * ti.storedChannels;
+    srx::Image src, dst;
+    src.base = static_cast<uint8_t*>(const_cast<void*>(in));
+    src.pitch = int64_t(inPitch);
+    src.frame = int64_t(inPitch) * h;
+    dst.base = static_cast<uint8_t*>(out);
+    dst.pitch = int64_t(outPitch);
+    dst.frame = int64_t(outPitch) * h * 2;
+
+    srx::LrFusedLaunch ll;
+    ll.image = src;
+    ll.a4 = a4;
+    ll.wpk1 = c->wpk1Rows8;
+    ll.wpk2 = c->wpkK32[1];
+    ll.wpk3 = c->wpkK32[2];
+    ll.wpkUp1 = c->wpkK32[3];
+    ll.bias = c->biasLrFused;
+    ll.width = int(w);
+    ll.height = int(h);
+    ll.batch = 1;
+    ll.mayAllocate = false;
+    SRX_HIP(srx::LaunchLrFused(ll, c->numCUs, st));
+
+    srx::HrFusedLaunch hl;
+    hl.a4 = a4;
+    hl.input = src;
+    hl.wpk4 = c->wpk[4];
+    hl.wpk5 = c->wpk[5];
+    hl.wpk6 = c->wpk6Rows16;
+    hl.bias4 = c->bias[4];
+    hl.bias5 = c->bias[5];
+    hl.image = dst;
+    hl.width2 = 2 * int(w);
+    hl.height2 = 2 * int(h);
+    hl.batch = 1;
+    hl.mayAllocate = false;
+    SRX_HIP(srx::LaunchHrFused(hl, c->numCUs, st));
+    return SRX_OK;
+}
+SRX_CATCH
+
+size_t srx_static_scratch_bytes(void) { return kStaticScratchBytes; }
 
 srx_status srx_tensor_to_image(srx_ctx* c, uint32_t frame, uint8_t* host, size_t pitch, void* stream) try
 {

@@ -385,6 +385,11 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     return pl;
 }
 
+hipError_t PrepareHrFused()
+{
+    return ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0>), kHrSmem);
+}
+
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
 {
     HrParams p{};

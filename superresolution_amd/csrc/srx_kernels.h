@@ -85,6 +85,10 @@ struct LrFusedLaunch
 };
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 
+// Load the two fused kernels on the current device and raise their shared-memory limits (otherwise done
+// by the first launch on that device).
+hipError_t PrepareFusedKernels();
+
 // How a fused kernel cuts `batch` frames into work items: strips of columns x segments of rows.
 // `steps` is the number of row steps one item takes (segment rows + the pipeline's warm-up rows) and
 // `rounds` how many items the busiest workgroup slot gets; steps * rounds / batch ranks plans.

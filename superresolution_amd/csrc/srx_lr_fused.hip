@@ -596,6 +596,14 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
     return pl;
 }
 
+hipError_t PrepareHrFused();
+
+hipError_t PrepareFusedKernels()
+{
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0>), kLrSmem);
+    return e != hipSuccess ? e : PrepareHrFused();
+}
+
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
 {
     LrParams p{};
