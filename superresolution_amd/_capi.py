@@ -63,6 +63,12 @@ def lib():
         import torch  # noqa: F401
     except Exception:
         pass
+    _lib = load_library(path)
+    return _lib
+
+
+def load_library(path):
+    """Load and type one build of libsrx.so (A/B timing loads several builds into one process)."""
     L = C.CDLL(path)
     vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_size_t
     L.srx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, u32, u32, u32, u32]
@@ -111,21 +117,20 @@ def lib():
     L.srx_frames_per_launch.restype = u32
     L.srx_static_scratch_bytes.restype = sz
     L.srx_pipe_slots.restype = u32
-    _lib = L
     return L
 
 
-def _check(status):
+def _check(status, library=None):
     if status != 0:
-        raise SrxError(status, lib().srx_last_error().decode(errors="replace"))
+        raise SrxError(status, (library or lib()).srx_last_error().decode(errors="replace"))
 
 
 class SuperResolutionContext:
     """One GPU's worth of the path: weights, workspace, input and output images in HBM."""
 
-    def __init__(self, width, height, batch=1, device=0, weights_path=None, flags=0):
+    def __init__(self, width, height, batch=1, device=0, weights_path=None, flags=0, library=None):
         self._h = C.c_void_p()
-        self._L = lib()
+        self._L = library or lib()
         _check(self._L.srx_create(C.byref(self._h), device, (weights_path or default_weights_path()).encode(),
                                   width, height, batch, flags))
         self.width, self.height, self.batch, self.flags = width, height, batch, flags

@@ -129,7 +129,7 @@ struct srx_ctx
     float* bias[srx::kNumConvLayers] = {};
     uint16_t* wpk6Rows16 = nullptr;          // conv6 as row-streaming 16x16x32 fragments (fused kernel)
     uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
-    uint16_t* wpkK32[4] = {};                // conv2, conv3, conv_up1 phases as 16x16x32 fragments (fused kernel), by layer
+    uint16_t* wpkK32[6] = {};                // conv2, conv3, conv_up1 phases, conv4, conv5 as 16x16x32 fragments (fused kernels), by layer
     float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
 
@@ -211,11 +211,11 @@ srx_status uploadWeights(srx_ctx* c)
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         c->wpk6Rows16 = static_cast<uint16_t*>(d);
     }
-    for (int l = 1; l <= 3; ++l)
+    for (int l = 1; l <= 5; ++l)
     {
         const uint32_t* sz = kConvLayers[l].sizes;
         const std::vector<uint16_t> packed = l == 3 ? PackConvUp1PhasesK32(c->folded.filter[l])
-                                                    : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]));
+                                                    : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]), l >= 4);
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
@@ -415,8 +415,8 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
         HrFusedLaunch hl;
         hl.a4 = c->tensor[SRX_T_CONV_UP1];
         hl.input = frameOffset(c->input, first);
-        hl.wpk4 = c->wpk[4];
-        hl.wpk5 = c->wpk[5];
+        hl.wpk4 = c->wpkK32[4];
+        hl.wpk5 = c->wpkK32[5];
         hl.wpk6 = c->wpk6Rows16;
         hl.bias4 = c->bias[4];
         hl.bias5 = c->bias[5];
@@ -758,8 +758,8 @@ srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* 
     srx::HrFusedLaunch hl;
     hl.a4 = a4;
     hl.input = src;
-    hl.wpk4 = c->wpk[4];
-    hl.wpk5 = c->wpk[5];
+    hl.wpk4 = c->wpkK32[4];
+    hl.wpk5 = c->wpkK32[5];
     hl.wpk6 = c->wpk6Rows16;
     hl.bias4 = c->bias[4];
     hl.bias5 = c->bias[5];
@@ -914,9 +914,8 @@ srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, siz
     const uint32_t* sz = srx::kConvLayers[layer].sizes;
     const std::vector<uint16_t> packed =
         layer == 0 ? srx::PackConv1Rows8(folded.filter[0])
-        : layer <= 2 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]))
         : layer == 3 ? srx::PackConvUp1PhasesK32(folded.filter[3])
-        : layer <= 5 ? srx::PackConv3x3(folded.filter[layer], int(sz[0]), int(sz[1]))
+        : layer <= 5 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]), layer >= 4)
                      : srx::PackConv6Rotating(folded.filter[6]);
     if (n) *n = packed.size();
     if (out)

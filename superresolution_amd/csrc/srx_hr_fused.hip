@@ -1,13 +1,15 @@
 // gfx950 kernel: conv4 -> conv5 -> conv6 -> + NN2x(input) -> UNORM8, fused.
 //
-// A workgroup (4 waves, 66 KB LDS, two workgroups per CU) walks a strip of
+// A workgroup (4 waves, 74 KB LDS, two workgroups per CU) walks a strip of
 // kHrStrip output columns downwards one row per step, keeping rolling windows of
 // conv_up1's output and of the two intermediate activations in LDS rings, so
 // neither intermediate touches HBM and no row is computed twice vertically.  One
 // LDS barrier separates steps.  Wave w accumulates, per step, its 32-pixel half
-// (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) with 18
-// v_mfma_f32_32x32x16_f16, and its 16-pixel quarter of conv6 with 3
-// v_mfma_f32_16x16x32_f16: every wave issues the same work.
+// (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) as four 16 x 16
+// accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap: all 32
+// input channels; the same cycles, LDS bytes and registers as 18 of the 32x32x16
+// shape, on which the chip holds a lower clock), and its 16-pixel quarter of conv6
+// with 3 more: every wave issues the same work.
 //
 // conv6 (32 -> 3 channels) streams input rows.  The 16 output rows of its MFMA are four
 // groups of (R, G, B, 0); group g accumulates the output row y with y mod 4 == g.  The
@@ -48,16 +50,16 @@ namespace {
 
 constexpr int kHrStrip = 60;
 constexpr int kHrRowPix = 66;
-constexpr int kHrStride32 = 80;                       // a4 / a5 pixel stride (odd number of 16-B slots)
-constexpr int kHrStride6 = 96;                        // a6 pixel stride: conflict-free for the 16x16x32 reads
-constexpr int kHrRow32 = kHrRowPix * kHrStride32;     // 5280
+constexpr int kHrStride32 = 96;                       // pixel stride of all three rings: 64 B of channels + 32 B, which makes
+constexpr int kHrStride6 = 96;                        // the 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
+constexpr int kHrRow32 = kHrRowPix * kHrStride32;     // 6336
 constexpr int kHrRow6 = kHrRowPix * kHrStride6;       // 6336
 constexpr int kHrA4 = 0;
 constexpr int kHrA5 = 4 * kHrRow32;
 constexpr int kHrA6 = 8 * kHrRow32;
-constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 67584
-constexpr int kAhead = 4;                             // LDS reads in flight ahead of their MFMA (4, 6, 8 measured: 4 is best by 1 %)
-constexpr int kMfmas = 21;                            // per step: 18 (conv4 or conv5) + 3 (conv6)
+constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 76032
+constexpr int kAhead = 4;                             // LDS reads in flight ahead of their first MFMA
+constexpr int kReads = 21;                            // per step: 18 (conv4 or conv5: 9 taps x 2 pixel halves) + 3 (conv6)
 
 struct HrParams
 {
@@ -77,8 +79,9 @@ template <int N>
 using IC = std::integral_constant<int, N>;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// EXP: 1 = pin every epilogue piece to its MFMA gap (default: the compiler places them, which measured
-// 2 % faster); 2 = no static priority.  Selected by env SRX_EXP (diagnostic).
+// EXP: 1 = let the compiler place the epilogue pieces (default: every piece is pinned to its MFMA gap; left to
+// itself the compiler bunches them at the head of the step, 10 % slower); 2 = no static priority.  Selected by
+// env SRX_EXP (diagnostic).
 template <int EXP>
 __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 {
@@ -87,8 +90,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int px = lane & 31, h = lane >> 5;      // 32x32x16 fragment coordinates
-    const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates
+    const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates: pixel (or output) within 16, group of 8 channels
     const int L = wave >> 1, ti = wave & 1;
 
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
@@ -105,11 +107,14 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
 #pragma unroll
         for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(w6[s]));
     }
-    f32x16 bias;
+    // Rows of the two 16-output halves are interleaved (PackConv3x3K32 with `interleave`): lane group q holds
+    // outputs 8q .. 8q+3 of the first half and 8q+4 .. 8q+7 of the second, i.e. 8 consecutive channels = one
+    // 16-byte LDS store per pixel instead of two 8-byte ones (which collide four ways at this pixel stride).
+    f32x4 biasLo, biasHi;
     {
         const float* src = L ? p.bias5 : p.bias4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = src[(r & 3) + 8 * (r >> 2) + 4 * h];
+        biasLo = *reinterpret_cast<const f32x4*>(src + 8 * q);
+        biasHi = *reinterpret_cast<const f32x4*>(src + 8 * q + 4);
     }
 
     // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe.  Workgroups b
@@ -129,8 +134,9 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int rot = L ? 1 : 0;                     // (-lag) & 3
     const int inRing = L ? kHrA5 : kHrA4;
     const int outRing = L ? kHrA6 : kHrA5;
-    const int outStride = L ? kHrStride6 : kHrStride32;
-    const int outRow = L ? kHrRow6 : kHrRow32;
+    constexpr int outStride = kHrStride32;
+    constexpr int outRow = kHrRow32;
+    static_assert(kHrStride6 == kHrStride32, "one pixel stride for all rings");
     int inSlot[4], outSlot[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -139,10 +145,10 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         outSlot[k] = outRing + ((k + rot) & 3) * outRow;
     }
     const int lag = L ? 3 : 0;
-    const int colOff = (L ? -1 : -2) + ti * 32 + px;
-    const int inLane = (ti * 32 + px) * kHrStride32 + h * 16;
+    const int colOff = (L ? -1 : -2) + ti * 32 + p16;              // + 16 for the second pixel half
+    const int inLane = (ti * 32 + p16) * kHrStride32 + q * 16;
     const int in6Lane = kHrA6 + (wave * 16 + p16) * kHrStride6 + q * 16;
-    const int outLane = (ti * 32 + px) * outStride + h * 8;
+    const int outLane = (ti * 32 + p16) * outStride + q * 16;
     // row loader: 66 pixels x 4 chunks of 16 B; thread t takes chunk t, and every wave also
     // takes the last 8 chunks (identical bytes to identical addresses: keeps the step branch-free)
     const int ldOff = kHrA4 + (tid >> 2) * kHrStride32 + (tid & 3) * 16;
@@ -188,8 +194,12 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * 4u;
         // the residual term: NN2x(input) at that pixel = input pixel (2B + (q >> 1), col6 >> 1)
         const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * 4u;
-        // conv4 / conv5: is this lane's column inside the image?
-        const bool colInside = X0 + colOff >= 0 && X0 + colOff < p.width2;
+        // conv4 / conv5: are this lane's two columns (one per 16-pixel half) inside the image?
+        const bool colInside0 = X0 + colOff >= 0 && X0 + colOff < p.width2;
+        const bool colInside1 = X0 + colOff + 16 >= 0 && X0 + colOff + 16 < p.width2;
+        // all 32 columns of this wave inside (wave-uniform): then only the rows can fall outside
+        const int colFirst = X0 + (L ? -1 : -2) + ti * 32;
+        const bool colsAllInside = colFirst >= 0 && colFirst + 31 < p.width2;
 
         __syncthreads();
         // rows Y0-3 .. Y0-1 go straight to LDS (slots of rows t0-1, t0, t0+1), row Y0 stays in flight
@@ -207,17 +217,21 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         uint4 rowAX = loadRow(ldSrcX), rowBX = rowAX;
         rowPtr += rowBytes;
         unsigned xraw = 0;                        // raw input pixel of the next block to store
-        f32x16 accA, accB;
+        // a 32-pixel x 32-output tile as four 16 x 16 accumulators: index = 2 * pixel half + output half
+        f32x4 accA[4], accB[4];
         f32x4 acc6 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         float hold0 = 0.0f, hold1 = 0.0f, hold2 = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.0f;
+        for (int a = 0; a < 4; ++a) accA[a] = accB[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
 
         // One step.  PH = (t - t0) & 3.
-        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
-                              const f32x16& accPrev, f32x16& acc) {
+        // MASKED = 0: every value this wave finishes in the step lies inside the image (the common case), so the
+        // zeroing of out-of-image activations is compiled out.
+        const auto stepImpl = [&](auto phase, auto masked, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
+                                  const f32x4 (&accPrev)[4], f32x4 (&acc)[4]) {
             constexpr int PH = decltype(phase)::value;
+            constexpr bool MASKED = decltype(masked)::value != 0;
             // ---- global loads: row t+3 (the last needed row is Y1+2: stop advancing there)
             load = loadRow(ldSrc);
             loadX = loadRow(ldSrcX);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
             // ---- row bookkeeping of what this step finishes
             const int rowDone = t - 1 - lag;                         // conv4 / conv5 row being finished
             const bool rowInside = rowDone >= 0 && rowDone < p.height2;
-            const bool inside = rowInside & colInside;
+            const bool inside0 = rowInside & colInside0, inside1 = rowInside & colInside1;
 
             // ---- LDS addresses of this step
             const char* in0 = smem + inSlot[(PH + 3) & 3] + inLane;  // rows rc-1, rc, rc+1 of the input ring
@@ -238,35 +252,41 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
             const char* c6 = smem + ((PH + 3) & 3) * kHrRow6 + in6Lane;    // row t-5 of a6
             char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;   // row rc-1 of the output ring
 
-            const auto readFrag = [&](auto kk) -> f16x8 {
-                constexpr int K = decltype(kk)::value;
-                if constexpr (K < 18)
+            // read R: filter tap R / 2 = (i, j) on the 16-pixel half R % 2 (all 32 channels: one K-step); 18.. = conv6
+            const auto readFrag = [&](auto rr) -> f16x8 {
+                constexpr int R = decltype(rr)::value;
+                if constexpr (R < 18)
                 {
-                    constexpr int i = K / 6, j = (K % 6) / 2, cc = K % 2;
+                    constexpr int tap = R / 2, half = R % 2, i = tap / 3, j = tap % 3;
                     const char* b = i == 0 ? in0 : (i == 1 ? in1 : in2);
-                    return *reinterpret_cast<const f16x8*>(b + j * kHrStride32 + cc * 32);
+                    return *reinterpret_cast<const f16x8*>(b + (half * 16 + j) * kHrStride32);
                 }
                 else
-                    return *reinterpret_cast<const f16x8*>(c6 + (K - 18) * kHrStride6);
+                    return *reinterpret_cast<const f16x8*>(c6 + (R - 18) * kHrStride6);
             };
 
             // epilogue state carried between the pieces below
-            f16x4 v0 = f16x4{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, res = v0, sum = v0, xin = v0;
+            f16x4 v0 = f16x4{0, 0, 0, 0}, v1 = v0, res = v0, sum = v0, xin = v0;
             unsigned c0 = 0, c1 = 0, c2 = 0;
-            const auto reluHalf4 = [&](int g) {
-                f16x4 v = to_half4(accPrev[4 * g], accPrev[4 * g + 1], accPrev[4 * g + 2], accPrev[4 * g + 3]);
+            // accumulator a of the finished row: outputs 16 * (a & 1) + 4q .. + 3 of pixel 16 * (a >> 1) + p16
+            const auto reluHalf4 = [&](int a) {
+                f16x4 v = to_half4(accPrev[a][0], accPrev[a][1], accPrev[a][2], accPrev[a][3]);
                 v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
-                return inside ? v : f16x4{0, 0, 0, 0};
+                if constexpr (!MASKED) return v;
+                return ((a >> 1) ? inside1 : inside0) ? v : f16x4{0, 0, 0, 0};
+            };
+            const auto store8 = [&](char* dst) {
+                *reinterpret_cast<f16x8*>(dst) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
             };
             // Piece K of the previous steps' epilogue, issued in the gap after MFMA K.
             const auto piece = [&](auto kk) {
                 constexpr int K = decltype(kk)::value;
                 constexpr int g = (PH + 3) & 3;      // conv6 group of the output row t-7, finished last step
                 if constexpr (K == 0) v0 = reluHalf4(0);
-                if constexpr (K == 1) { *reinterpret_cast<f16x4*>(outDst) = v0; v1 = reluHalf4(1); }
-                if constexpr (K == 2) { *reinterpret_cast<f16x4*>(outDst + 16) = v1; v2 = reluHalf4(2); }
-                if constexpr (K == 3) { *reinterpret_cast<f16x4*>(outDst + 32) = v2; v3 = reluHalf4(3); }
-                if constexpr (K == 4) *reinterpret_cast<f16x4*>(outDst + 48) = v3;
+                if constexpr (K == 1) v1 = reluHalf4(1);
+                if constexpr (K == 2) { store8(outDst); v0 = reluHalf4(2); }
+                if constexpr (K == 3) v1 = reluHalf4(3);
+                if constexpr (K == 4) store8(outDst + 16 * outStride);
                 if constexpr (K == 5)
                 {
                     hold0 = qIs[g] ? acc6[0] : hold0;
@@ -308,31 +328,60 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
                 }
             };
 
-            // ---- the MFMA stream: reads run kAhead in front, one epilogue piece per gap
-            f16x8 bq[kMfmas];
+            // ---- the MFMA stream: reads run kAhead in front; two epilogue pieces per K-step of four MFMAs
+            f16x8 bq[kReads];
             constexpr int rho = (PH + 1) & 3;        // (t - 5) mod 4
+            const auto fetch = [&](auto rr) {
+                constexpr int R = decltype(rr)::value;
+                if constexpr (R < kReads) bq[R] = readFrag(rr);
+            };
+            // K-step k = filter tap k of the conv4 / conv5 chain; the first takes the bias as its C operand
             const auto body = [&](auto kk) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K + kAhead < kMfmas) bq[K + kAhead] = readFrag(IC<K + kAhead>{});
-                // the first MFMA of the conv4 / conv5 chain takes the bias as its C operand
-                if constexpr (K == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[0], bq[0], bias, 0, 0, 0);
-                else if constexpr (K < 18) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wmain[K], bq[K], acc, 0, 0, 0);
-                else acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + (K - 18)], bq[K], acc6, 0, 0, 0);
-                piece(kk);
-                if ((EXP & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+                fetch(IC<2 * K + kAhead>{});
+                fetch(IC<2 * K + kAhead + 1>{});
+                if constexpr (K == 0)
+                {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], bq[0], biasLo, 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], bq[0], biasHi, 0, 0, 0);
+                    piece(IC<0>{});
+                    if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], bq[1], biasLo, 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], bq[1], biasHi, 0, 0, 0);
+                }
+                else
+                {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], bq[2 * K], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], bq[2 * K], acc[1], 0, 0, 0);
+                    piece(IC<2 * K>{});
+                    if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], bq[2 * K + 1], acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], bq[2 * K + 1], acc[3], 0, 0, 0);
+                }
+                piece(IC<2 * K + 1>{});
+                if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             };
-            bq[0] = readFrag(IC<0>{}); bq[1] = readFrag(IC<1>{}); bq[2] = readFrag(IC<2>{});
-            bq[3] = readFrag(IC<3>{});
-            if ((EXP & 1) != 0) __builtin_amdgcn_sched_barrier(0);
-            body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{}); body(IC<5>{});
-            body(IC<6>{}); body(IC<7>{}); body(IC<8>{}); body(IC<9>{}); body(IC<10>{}); body(IC<11>{});
-            body(IC<12>{}); body(IC<13>{}); body(IC<14>{}); body(IC<15>{}); body(IC<16>{}); body(IC<17>{});
-            body(IC<18>{}); body(IC<19>{}); body(IC<20>{});
+            fetch(IC<0>{}); fetch(IC<1>{}); fetch(IC<2>{}); fetch(IC<3>{});
+            if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{});
+            body(IC<5>{}); body(IC<6>{}); body(IC<7>{}); body(IC<8>{});
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 0], bq[18], acc6, 0, 0, 0);
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 1], bq[19], acc6, 0, 0, 0);
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 2], bq[20], acc6, 0, 0, 0);
 
             // ---- park row t+2
             *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
             *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
             barrierLds();
+        };
+
+        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
+                              const f32x4 (&accPrev)[4], f32x4 (&acc)[4]) {
+            const int rowDone = t - 1 - lag;
+            if (colsAllInside && rowDone >= 0 && rowDone < p.height2)
+                stepImpl(phase, IC<0>{}, t, park, parkX, load, loadX, accPrev, acc);
+            else
+                stepImpl(phase, IC<1>{}, t, park, parkX, load, loadX, accPrev, acc);
         };
 
         // steps t0 .. tLast + 3; the three steps after the last store touch only ring rows nothing

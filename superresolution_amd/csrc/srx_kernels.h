@@ -61,7 +61,7 @@ struct HrFusedLaunch
 {
     Tensor a4;
     Image input;                     // RGBA8 input image: the residual term is NN2x of its tensor value
-    const uint16_t *wpk4 = nullptr, *wpk5 = nullptr, *wpk6 = nullptr;   // wpk6: PackConv6Rotating
+    const uint16_t *wpk4 = nullptr, *wpk5 = nullptr, *wpk6 = nullptr;   // PackConv3x3K32, PackConv3x3K32, PackConv6Rotating
     const float *bias4 = nullptr, *bias5 = nullptr;
     Image image;
     int width2 = 0, height2 = 0;     // size of the 2x grid

@@ -463,7 +463,7 @@ std::vector<uint16_t> ConvUp1PhaseFilters(const std::vector<uint16_t>& oihw)
     return out;
 }
 
-std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout, int cin)
+std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout, int cin, bool interleave)
 {
     const int tiles = (cout + 31) / 32, kchunks = cin / 32, ksteps = 9 * kchunks;
     std::vector<uint16_t> out(size_t(tiles) * ksteps * 2 * 64 * 8, 0);
@@ -473,7 +473,10 @@ std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout
                 for (int half = 0; half < 2; ++half)
                     for (int lane = 0; lane < 64; ++lane)
                     {
-                        const int o = t * 32 + half * 16 + (lane & 15), q = lane >> 4;
+                        const int r = lane & 15, q = lane >> 4;
+                        // output of MFMA row r of this half: plain, or interleaved so that the four rows a lane
+                        // group gets of either half are eight consecutive outputs
+                        const int o = t * 32 + (interleave ? 8 * (r >> 2) + 4 * half + (r & 3) : half * 16 + r);
                         if (o >= cout) continue;
                         const size_t dst = (((size_t(t) * ksteps + tap * kchunks + kc) * 2 + half) * 64 + lane) * 8;
                         for (int j = 0; j < 8; ++j) out[dst + j] = oihw[(size_t(o) * cin + kc * 32 + 8 * q + j) * 9 + tap];
