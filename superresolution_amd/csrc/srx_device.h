@@ -91,7 +91,7 @@ enum ProbedKernel { PROBE_LR_FUSED = 0, PROBE_HR_FUSED = 1, PROBE_COUNT };
 // The probe of `kernel` on the current device, with its buffer allocated; nullptr when SRX_CLOCK is unset,
 // when `blocks` exceeds the buffer, or when `mayAllocate` is false and the buffer does not exist yet.
 ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate);
-void clockProbeReport(ClockProbe* probe, const char* name, int blocks, hipStream_t s);
+void clockProbeReport(ClockProbe* probe, const char* name, int blocks, hipStream_t s, int extraWords = 0);
 
 // Raise a kernel's dynamic shared memory limit, once per (device, kernel).  Thread-safe.
 hipError_t ensureDynamicLds(const void* kernel, int bytes);

@@ -1,27 +1,36 @@
 // gfx950 kernel: conv4 -> conv5 -> conv6 -> + NN2x(input) -> UNORM8, fused.
 //
-// A workgroup (4 waves, 74 KB LDS, two workgroups per CU) walks a strip of
-// kHrStrip output columns downwards one row per step, keeping rolling windows of
-// conv_up1's output and of the two intermediate activations in LDS rings, so
-// neither intermediate touches HBM and no row is computed twice vertically.  One
-// LDS barrier separates steps.  Wave w accumulates, per step, its 32-pixel half
-// (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) as four 16 x 16
-// accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap: all 32
-// input channels; the same cycles, LDS bytes and registers as 18 of the 32x32x16
-// shape, on which the chip holds a lower clock), and its 16-pixel quarter of conv6
-// with 3 more: every wave issues the same work.
+// A workgroup of eight waves (one per CU, 152 KB LDS) walks TWO strips of kHrStrip output columns
+// downwards, one row per step: waves 0-3 (group 0) own one strip, waves 4-7 (group 1) the next, each
+// with rolling windows of conv_up1's output and of the two intermediate activations in its own LDS
+// rings, so neither intermediate touches HBM and no row is computed twice vertically.  Wave w of a
+// group accumulates, per step, its 32-pixel half (w & 1) of one row of conv4 (w < 2) or conv5
+// (w >= 2) as four 16 x 16 accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap:
+// all 32 input channels), and its 16-pixel quarter of conv6 with 3 more: every wave issues the same
+// work.
+//
+// The two groups alternate.  A step of a group has a LOAD phase (the first twelve activation
+// fragments of the step are fetched from LDS, the previous step's accumulators are converted and
+// stored to the rings, finished conv6 rows are converted and written to the image, the next
+// conv_up1 row is parked in LDS and the one after it requested from HBM) and a MATRIX phase (the 39
+// MFMAs, with the remaining fragment reads running ahead of them).  Waves w and w + 4 share a SIMD
+// and its one matrix pipe; group 1 runs half a step behind group 0, so while one wave of a SIMD
+// streams MFMAs its partner does its vector, LDS-store and memory work, and the other way round
+// after the next barrier (one workgroup barrier per phase).  The matrix pipe then idles only for
+// the barrier itself, not for LDS latency or epilogues, and the two strips of a CU advance in lock
+// step instead of one workgroup starving the other.
 //
 // conv6 (32 -> 3 channels) streams input rows.  The 16 output rows of its MFMA are four
 // groups of (R, G, B, 0); group g accumulates the output row y with y mod 4 == g.  The
 // newest row R of conv5's output adds filter row 2 to output row R-1, filter row 1 to R
 // and filter row 0 to R+1 in ONE MFMA per horizontal tap (filter fragments per R mod 4:
-// PackConv6Rotating), so conv6 costs 3 MFMAs per step instead of 9 and reads each
-// activation fragment once.  A finished row is moved to a holding register and its group
-// cleared; every fourth step all 64 lanes convert and store a block of four rows.
+// PackConv6Rotating; the fragments of R mod 4 == rho are those of rho == 0 with the 16 rows
+// rotated by 4 rho, so LDS holds the three of rho == 0 and a lane reads its rotated row), so conv6
+// costs 3 MFMAs per step instead of 9 and reads each activation fragment once.  A finished row is
+// moved to a holding register and its group cleared; every fourth step all 64 lanes convert and
+// store a block of four rows.
 //
-// Software pipeline: what step t accumulates is converted and stored by step t+1,
-// a few VALU instructions in each gap between that step's MFMAs, so the epilogue
-// runs under the matrix pipe instead of after it.  Rows per step t:
+// Rows per step t of a group:
 //     accumulate: conv4 row t      conv5 row t-3     conv6 input row t-5
 //     finish:     conv4 row t-1    conv5 row t-4     conv6 output row t-7 -> holding register
 // The loop is unrolled by four so every ring slot and conv6 group is a compile-time
@@ -48,18 +57,18 @@ using namespace dev;
 
 namespace {
 
+constexpr int kHrThreads = 512;
 constexpr int kHrStrip = 60;
 constexpr int kHrRowPix = 66;
-constexpr int kHrStride32 = 96;                       // pixel stride of all three rings: 64 B of channels + 32 B, which makes
-constexpr int kHrStride6 = 96;                        // the 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
-constexpr int kHrRow32 = kHrRowPix * kHrStride32;     // 6336
-constexpr int kHrRow6 = kHrRowPix * kHrStride6;       // 6336
-constexpr int kHrA4 = 0;
-constexpr int kHrA5 = 4 * kHrRow32;
-constexpr int kHrA6 = 8 * kHrRow32;
-constexpr int kHrSmem = 8 * kHrRow32 + 4 * kHrRow6;   // 76032
-constexpr int kAhead = 4;                             // LDS reads in flight ahead of their first MFMA
-constexpr int kReads = 21;                            // per step: 18 (conv4 or conv5: 9 taps x 2 pixel halves) + 3 (conv6)
+constexpr int kHrStride = 96;                         // pixel stride of all three rings: 64 B of channels + 32 B, which makes the
+                                                      // 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
+constexpr int kHrRow = kHrRowPix * kHrStride;         // 6336
+constexpr int kHrA4 = 0;                              // per group: three rings of four rows
+constexpr int kHrA5 = 4 * kHrRow;
+constexpr int kHrA6 = 8 * kHrRow;
+constexpr int kHrGroupSmem = 12 * kHrRow;             // 76032
+constexpr int kHrW6 = 2 * kHrGroupSmem;               // conv6 filter fragments of rho == 0: [tap j][lane][16 B]
+constexpr int kHrSmem = kHrW6 + 3 * 1024;             // 155136
 
 struct HrParams
 {
@@ -79,33 +88,42 @@ template <int N>
 using IC = std::integral_constant<int, N>;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// EXP: 1 = let the compiler place the epilogue pieces (default: every piece is pinned to its MFMA gap; left to
-// itself the compiler bunches them at the head of the step, 10 % slower); 2 = no static priority.  Selected by
-// env SRX_EXP (diagnostic).
-template <int EXP>
-__global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
+// The barrier between two phases.  LDS traffic only is ordered (see barrierLds); the scheduling fences keep the
+// compiler from moving matrix or vector instructions from one phase into the other.
+__device__ __forceinline__ void phaseBarrier()
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __builtin_amdgcn_sched_barrier(0);
+    barrierLds();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// EXP (diagnostic build variants, env SRX_EXP): 1 = no scheduling pins inside the phases; 2 = no raised priority
+// in the matrix phase; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave spends in the
+// load phase, waiting at its barrier, in the matrix phase and waiting at that barrier.
+template <int EXP>
+__global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smemAll[];
+    constexpr bool PIN = (EXP & 1) == 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int G = wave >> 2;                      // group = strip of the pair
+    const int w4 = wave & 3, gtid = tid & 255;    // wave and thread within the group
     const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates: pixel (or output) within 16, group of 8 channels
-    const int L = wave >> 1, ti = wave & 1;
+    const int L = w4 >> 1, ti = w4 & 1;
+    char* const smem = smemAll + G * kHrGroupSmem;
 
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
-    f16x8 wmain[18], w6[12];
+    f16x8 wmain[18];
     {
         const f16x8* src = L ? p.wpk5 : p.wpk4;
 #pragma unroll
         for (int s = 0; s < 18; ++s) wmain[s] = src[s * 64 + lane];
-#pragma unroll
-        for (int s = 0; s < 12; ++s) w6[s] = p.wpk6[s * 64 + lane];
         // make the loads land here, not behind vmcnt waits inside the step loop
 #pragma unroll
         for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(wmain[s]));
-#pragma unroll
-        for (int s = 0; s < 12; ++s) asm volatile("" ::"v"(w6[s]));
     }
     // Rows of the two 16-output halves are interleaved (PackConv3x3K32 with `interleave`): lane group q holds
     // outputs 8q .. 8q+3 of the first half and 8q+4 .. 8q+7 of the second, i.e. 8 consecutive channels = one
@@ -117,15 +135,13 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         biasHi = *reinterpret_cast<const f32x4*>(src + 8 * q + 4);
     }
 
-    // Two workgroups share a CU, so two waves share each SIMD and its one MFMA pipe.  Workgroups b
-    // and b + #CUs share a CU; the second gets a higher wave priority.  Measured, that changes
-    // nothing (priority 0, 1 or 3: one workgroup of each pair gets about 65 % of the pipe and
-    // finishes first either way, and a pair made to advance evenly is slower in aggregate); it is
-    // kept so that which of the two runs ahead does not depend on arbitration details.
-    if ((EXP & 2) == 0 && ((blockIdx.x / (gridDim.x >> 1 ? gridDim.x >> 1 : 1)) & 1)) __builtin_amdgcn_s_setprio(1);
-
     // never-written pad columns of the rings must hold finite values
-    for (int i = tid * 16; i < kHrSmem; i += kThreads * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
+    for (int i = tid * 16; i < kHrW6; i += kHrThreads * 16) *reinterpret_cast<uint4*>(smemAll + i) = uint4{0, 0, 0, 0};
+    if (tid < 192) reinterpret_cast<uint4*>(smemAll + kHrW6)[tid] = reinterpret_cast<const uint4*>(p.wpk6)[tid];
+    // conv6 filter fragment of (rho, tap j) for this lane: row (p16 - 4 rho) & 15 of the rho == 0 fragment
+    int w6Lane[4];
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) w6Lane[rho] = kHrW6 + ((((p16 - 4 * rho) & 15) + 16 * q) * 16);
 
     // Ring slots.  Row r of an item lives in slot (r - t0) & 3, t0 = the item's first step.  With
     // the loop unrolled by four the phase PH = (t - t0) & 3 is a compile-time constant, and so is
@@ -134,27 +150,27 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     const int rot = L ? 1 : 0;                     // (-lag) & 3
     const int inRing = L ? kHrA5 : kHrA4;
     const int outRing = L ? kHrA6 : kHrA5;
-    constexpr int outStride = kHrStride32;
-    constexpr int outRow = kHrRow32;
-    static_assert(kHrStride6 == kHrStride32, "one pixel stride for all rings");
     int inSlot[4], outSlot[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-        inSlot[k] = inRing + ((k + rot) & 3) * kHrRow32;
-        outSlot[k] = outRing + ((k + rot) & 3) * outRow;
+        inSlot[k] = inRing + ((k + rot) & 3) * kHrRow;
+        outSlot[k] = outRing + ((k + rot) & 3) * kHrRow;
     }
     const int lag = L ? 3 : 0;
     const int colOff = (L ? -1 : -2) + ti * 32 + p16;              // + 16 for the second pixel half
-    const int inLane = (ti * 32 + p16) * kHrStride32 + q * 16;
-    const int in6Lane = kHrA6 + (wave * 16 + p16) * kHrStride6 + q * 16;
-    const int outLane = (ti * 32 + p16) * outStride + q * 16;
-    // row loader: 66 pixels x 4 chunks of 16 B; thread t takes chunk t, and every wave also
-    // takes the last 8 chunks (identical bytes to identical addresses: keeps the step branch-free)
-    const int ldOff = kHrA4 + (tid >> 2) * kHrStride32 + (tid & 3) * 16;
+    const int inLane = (ti * 32 + p16) * kHrStride + q * 16;
+    const int in6Lane = kHrA6 + (w4 * 16 + p16) * kHrStride + q * 16;
+    const int outLane = (ti * 32 + p16) * kHrStride + q * 16;
+    // Row loader: 66 pixels x 4 chunks of 16 B; thread t of the group takes chunk t & 3 of a pixel, and every wave
+    // also takes the last 8 chunks (identical bytes to identical addresses: keeps the step branch-free).  Within
+    // four pixels the order is 0, 2, 1, 3: eight consecutive lanes then write eight different 16-byte bank groups.
+    const int ldPixRaw = gtid >> 2;
+    const int ldPix = (ldPixRaw & ~3) | ((ldPixRaw & 1) << 1) | ((ldPixRaw >> 1) & 1);
+    const int ldOff = kHrA4 + ldPix * kHrStride + (gtid & 3) * 16;
     const int ldPixX = min(64 + (lane >> 2), kHrRowPix - 1);
-    const int ldOffX = kHrA4 + ldPixX * kHrStride32 + (lane & 3) * 16;
-    const int ldSrc = (tid >> 2) * 64 + (tid & 3) * 16;         // byte offsets within an a4 row
+    const int ldOffX = kHrA4 + ldPixX * kHrStride + (lane & 3) * 16;
+    const int ldSrc = ldPix * 64 + (gtid & 3) * 16;             // byte offsets within an a4 row
     const int ldSrcX = ldPixX * 64 + (lane & 3) * 16;
     // conv6: lane group q holds the output row y with y mod 4 == q
     bool qIs[4];
@@ -162,16 +178,29 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
     for (int g = 0; g < 4; ++g) qIs[g] = q == g;
 
     const int perFrame = p.strips * p.segs;
-    for (TileWalk tw(p.numItems); tw.valid(); tw.next())
+    // iterations of four steps an item takes: steps t0 = Y0 - 2 .. tLast + 3, tLast = the step that stores the last
+    // block of four rows
+    const auto itersOf = [&](int item) {
+        const int rem = item % perFrame;
+        const int Y0 = (rem / p.strips) * p.segRows;
+        const int Y1 = min(p.height2, Y0 + p.segRows);
+        return ((((Y1 - 1) & ~3) + 12 - Y0) >> 2) + 1;
+    };
+    const int numPairs = (p.numItems + 1) >> 1;
+    for (TileWalk tw(numPairs); tw.valid(); tw.next())
     {
-        const int f = tw.cur / perFrame;
-        const int rem = tw.cur - f * perFrame;
+        // the pair's items; an odd item count leaves the last group 1 a copy of the last item that stores nothing
+        const int itemRaw = 2 * tw.cur + G;
+        const bool itemValid = itemRaw < p.numItems;
+        const int item = itemValid ? itemRaw : p.numItems - 1;
+        const int iters = max(itersOf(min(2 * tw.cur, p.numItems - 1)), itersOf(min(2 * tw.cur + 1, p.numItems - 1)));
+        const int f = item / perFrame;
+        const int rem = item - f * perFrame;
         const int seg = rem / p.strips;
         const int X0 = (rem - seg * p.strips) * kHrStrip;
         const int Y0 = seg * p.segRows;                       // a multiple of 4
         const int Y1 = min(p.height2, Y0 + p.segRows);
         const int t0 = Y0 - 2;
-        const int tLast = ((Y1 - 1) & ~3) + 10;               // the step that stores the last block of four rows
 
         const long rowBytes = long(p.a4.pitch) * 64;
         // the a4 row to fetch next (uniform): one buffer descriptor per row, lanes add their chunk offset
@@ -189,8 +218,8 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
             const_cast<uint8_t*>(p.input) + f * p.inputFrame, 0, int(p.inputFrame), 0x00020000);
 
         // conv6: lane (p16, q) finishes the pixel (row 4B + q, column col6) of a block of rows 4B .. 4B+3
-        const int col6 = X0 + wave * 16 + p16;
-        const bool laneOwns = wave * 16 + p16 < kHrStrip && col6 < p.width2;
+        const int col6 = X0 + w4 * 16 + p16;
+        const bool laneOwns = itemValid && w4 * 16 + p16 < kHrStrip && col6 < p.width2;
         const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * 4u;
         // the residual term: NN2x(input) at that pixel = input pixel (2B + (q >> 1), col6 >> 1)
         const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * 4u;
@@ -207,8 +236,8 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         for (int rr = 0; rr < 3; ++rr)
         {
             const int slot = (rr - 1) & 3;       // row t0 - 1 + rr
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOff) = loadRow(ldSrc);
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow32 + ldOffX) = loadRow(ldSrcX);
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow + ldOff) = loadRow(ldSrc);
+            *reinterpret_cast<uint4*>(smem + slot * kHrRow + ldOffX) = loadRow(ldSrcX);
             rowPtr += rowBytes;
         }
         // Rows in flight in registers: step t issues the load of row t+3 into one register set and
@@ -217,182 +246,178 @@ __global__ __launch_bounds__(kThreads, 2) void HrFusedKernel(const HrParams p)
         uint4 rowAX = loadRow(ldSrcX), rowBX = rowAX;
         rowPtr += rowBytes;
         unsigned xraw = 0;                        // raw input pixel of the next block to store
-        // a 32-pixel x 32-output tile as four 16 x 16 accumulators: index = 2 * pixel half + output half
-        f32x4 accA[4], accB[4];
+        // a 32-pixel x 32-output tile as four 16 x 16 accumulators: index = 2 * pixel half + output half.  One
+        // set is enough: a step's load phase converts and stores it before the matrix phase starts it anew.
+        f32x4 acc[4];
         f32x4 acc6 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         float hold0 = 0.0f, hold1 = 0.0f, hold2 = 0.0f;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) accA[a] = accB[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
+        // Activation fragments stay in registers for the three steps that use their row (as filter row 2, 1,
+        // 0): fr[s] holds the row of ring slot s, [tap j * 2 + pixel half]; a step fetches only its newest row.
+        // The two older rows of the first step are fetched here.
+        f16x8 fr[4][6];
+        const auto fetchRow = [&](auto set, const char* rowBase) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                    fr[S][j * 2 + half] = *reinterpret_cast<const f16x8*>(rowBase + (half * 16 + j) * kHrStride);
+        };
+        fetchRow(IC<3>{}, smem + inSlot[3] + inLane);
+        fetchRow(IC<0>{}, smem + inSlot[0] + inLane);
 
-        // One step.  PH = (t - t0) & 3.
-        // MASKED = 0: every value this wave finishes in the step lies inside the image (the common case), so the
-        // zeroing of out-of-image activations is compiled out.
-        const auto stepImpl = [&](auto phase, auto masked, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
-                                  const f32x4 (&accPrev)[4], f32x4 (&acc)[4]) {
+        unsigned long long spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // One step = load phase, barrier, matrix phase, barrier.  PH = (t - t0) & 3.
+        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX) {
             constexpr int PH = decltype(phase)::value;
-            constexpr bool MASKED = decltype(masked)::value != 0;
-            // ---- global loads: row t+3 (the last needed row is Y1+2: stop advancing there)
+            constexpr int rho = (PH + 1) & 3;        // (t - 5) mod 4
+
+            // ---- LDS addresses of this step
+            const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;        // the newest row (rc+1) of the input ring
+            const char* c6 = smem + ((PH + 3) & 3) * kHrRow + in6Lane;     // row t-5 of a6
+            char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;         // row rc-1 of the output ring
+
+            unsigned long long stamp = 0;
+            const auto lap = [&](int k) {
+                if constexpr ((EXP & 4) != 0)
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (k >= 0) spent[k] += now - stamp;
+                    stamp = now;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            lap(-1);
+            // ================= load phase =================
+            // the step's LDS reads: the newest input row (six fragments) and conv6's three
+            fetchRow(IC<(PH + 1) & 3>{}, in2);
+            f16x8 b6[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b6[j] = *reinterpret_cast<const f16x8*>(c6 + j * kHrStride);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+            // global loads: row t+3 (the last needed row is Y1+2: stop advancing there)
             load = loadRow(ldSrc);
             loadX = loadRow(ldSrcX);
             rowPtr += (t + 3 < Y1 + 2) ? rowBytes : 0;
             // the block of rows stored three steps from now starts at row t - 7 (phase 1 only)
             if constexpr (PH == 1)
                 xraw = __builtin_amdgcn_raw_buffer_load_b32(inputRsrc, int(laneX0 + unsigned((t - 7) >> 1) * unsigned(p.inputPitch)), 0, 0);
+            lap(0);
 
-            // ---- row bookkeeping of what this step finishes
+            // the previous step's epilogue.  MASKED = 0: every value this wave finishes lies inside the image (the
+            // common case), so the zeroing of out-of-image activations is compiled out.
             const int rowDone = t - 1 - lag;                         // conv4 / conv5 row being finished
             const bool rowInside = rowDone >= 0 && rowDone < p.height2;
-            const bool inside0 = rowInside & colInside0, inside1 = rowInside & colInside1;
+            const auto epilogue = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value != 0;
+                const bool inside0 = rowInside & colInside0, inside1 = rowInside & colInside1;
+                // accumulator a of the finished row: outputs 8q + 4 * (a & 1) .. + 3 of pixel 16 * (a >> 1) + p16
+                const auto reluHalf4 = [&](int a) {
+                    f16x4 v = to_half4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+                    v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
+                    if constexpr (!MASKED) return v;
+                    return ((a >> 1) ? inside1 : inside0) ? v : f16x4{0, 0, 0, 0};
+                };
+                *reinterpret_cast<f16x8*>(outDst) = __builtin_shufflevector(reluHalf4(0), reluHalf4(1), 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<f16x8*>(outDst + 16 * kHrStride) =
+                    __builtin_shufflevector(reluHalf4(2), reluHalf4(3), 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            if (colsAllInside && rowInside) epilogue(IC<0>{});
+            else epilogue(IC<1>{});
+            lap(1);
 
-            // ---- LDS addresses of this step
-            const char* in0 = smem + inSlot[(PH + 3) & 3] + inLane;  // rows rc-1, rc, rc+1 of the input ring
-            const char* in1 = smem + inSlot[PH] + inLane;
-            const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;
-            const char* c6 = smem + ((PH + 3) & 3) * kHrRow6 + in6Lane;    // row t-5 of a6
-            char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;   // row rc-1 of the output ring
+            // conv6: the output row t-7 was finished by the last matrix phase; its group is (PH + 3) & 3
+            {
+                constexpr int g = (PH + 3) & 3;
+                hold0 = qIs[g] ? acc6[0] : hold0;
+                hold1 = qIs[g] ? acc6[1] : hold1;
+                hold2 = qIs[g] ? acc6[2] : hold2;
+                acc6[0] = qIs[g] ? 0.0f : acc6[0];
+                acc6[1] = qIs[g] ? 0.0f : acc6[1];
+                acc6[2] = qIs[g] ? 0.0f : acc6[2];
+            }
+            // every fourth step: the block of rows t-10 .. t-7 is complete in the holding registers;
+            // lane (p16, q) converts and stores pixel (row t-10+q, column col6)
+            if constexpr (PH == 0)
+            {
+                // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
+                constexpr float k = 1.0f / 255.0f;
+                const f16x4 xin = to_half4(float(xraw & 0xff) * k, float((xraw >> 8) & 0xff) * k, float((xraw >> 16) & 0xff) * k, 0.0f);
+                const f16x4 res = to_half4(hold0, hold1, hold2, 0.0f);
+                const f16x4 sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
+                                           (float)res[2] + (float)xin[2], 0.0f);
+                const unsigned c0 = unorm8((float)sum[0]), c1 = unorm8((float)sum[1]), c2 = unorm8((float)sum[2]);
+                // branch-free: lanes that own no pixel, and blocks above the segment, store at an
+                // offset beyond the descriptor's range, which the hardware drops
+                const int blk = t - 10;
+                const bool ok = laneOwns & (blk >= Y0);
+                const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
+            }
+            lap(2);
+            // park row t+2
+            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow + ldOff) = park;
+            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow + ldOffX) = parkX;
+            if constexpr ((EXP & 4) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lap(3);
+            phaseBarrier();
+            lap(4);
 
-            // read R: filter tap R / 2 = (i, j) on the 16-pixel half R % 2 (all 32 channels: one K-step); 18.. = conv6
-            const auto readFrag = [&](auto rr) -> f16x8 {
-                constexpr int R = decltype(rr)::value;
-                if constexpr (R < 18)
-                {
-                    constexpr int tap = R / 2, half = R % 2, i = tap / 3, j = tap % 3;
-                    const char* b = i == 0 ? in0 : (i == 1 ? in1 : in2);
-                    return *reinterpret_cast<const f16x8*>(b + (half * 16 + j) * kHrStride32);
-                }
-                else
-                    return *reinterpret_cast<const f16x8*>(c6 + (R - 18) * kHrStride6);
-            };
-
-            // epilogue state carried between the pieces below
-            f16x4 v0 = f16x4{0, 0, 0, 0}, v1 = v0, res = v0, sum = v0, xin = v0;
-            unsigned c0 = 0, c1 = 0, c2 = 0;
-            // accumulator a of the finished row: outputs 16 * (a & 1) + 4q .. + 3 of pixel 16 * (a >> 1) + p16
-            const auto reluHalf4 = [&](int a) {
-                f16x4 v = to_half4(accPrev[a][0], accPrev[a][1], accPrev[a][2], accPrev[a][3]);
-                v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
-                if constexpr (!MASKED) return v;
-                return ((a >> 1) ? inside1 : inside0) ? v : f16x4{0, 0, 0, 0};
-            };
-            const auto store8 = [&](char* dst) {
-                *reinterpret_cast<f16x8*>(dst) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-            };
-            // Piece K of the previous steps' epilogue, issued in the gap after MFMA K.
-            const auto piece = [&](auto kk) {
-                constexpr int K = decltype(kk)::value;
-                constexpr int g = (PH + 3) & 3;      // conv6 group of the output row t-7, finished last step
-                if constexpr (K == 0) v0 = reluHalf4(0);
-                if constexpr (K == 1) v1 = reluHalf4(1);
-                if constexpr (K == 2) { store8(outDst); v0 = reluHalf4(2); }
-                if constexpr (K == 3) v1 = reluHalf4(3);
-                if constexpr (K == 4) store8(outDst + 16 * outStride);
-                if constexpr (K == 5)
-                {
-                    hold0 = qIs[g] ? acc6[0] : hold0;
-                    hold1 = qIs[g] ? acc6[1] : hold1;
-                    hold2 = qIs[g] ? acc6[2] : hold2;
-                }
-                if constexpr (K == 6)
-                {
-                    acc6[0] = qIs[g] ? 0.0f : acc6[0];
-                    acc6[1] = qIs[g] ? 0.0f : acc6[1];
-                    acc6[2] = qIs[g] ? 0.0f : acc6[2];
-                }
-                // every fourth step: the block of rows t-10 .. t-7 is complete in the holding registers;
-                // lane (p16, q) converts and stores pixel (row t-10+q, column col6)
-                if constexpr (PH == 0)
-                {
-                    if constexpr (K == 7)
-                    {
-                        // CSImageToTensor on the fly: UNORM8 -> u/255 -> fp16 (u * (1/255) rounds to the same fp16)
-                        constexpr float k = 1.0f / 255.0f;
-                        xin = to_half4(float(xraw & 0xff) * k, float((xraw >> 8) & 0xff) * k, float((xraw >> 16) & 0xff) * k, 0.0f);
-                    }
-                    if constexpr (K == 8) res = to_half4(hold0, hold1, hold2, 0.0f);
-                    if constexpr (K == 9)
-                        sum = to_half4((float)res[0] + (float)xin[0], (float)res[1] + (float)xin[1],
-                                       (float)res[2] + (float)xin[2], 0.0f);
-                    if constexpr (K == 10) c0 = unorm8((float)sum[0]);
-                    if constexpr (K == 11) c1 = unorm8((float)sum[1]);
-                    if constexpr (K == 12) c2 = unorm8((float)sum[2]);
-                    if constexpr (K == 13)
-                    {
-                        // branch-free: lanes that own no pixel, and blocks above the segment, store at an
-                        // offset beyond the descriptor's range, which the hardware drops
-                        const int blk = t - 10;
-                        const bool ok = laneOwns & (blk >= Y0);
-                        const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xffffffffu;
-                        __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
-                    }
-                }
-            };
-
-            // ---- the MFMA stream: reads run kAhead in front; two epilogue pieces per K-step of four MFMAs
-            f16x8 bq[kReads];
-            constexpr int rho = (PH + 1) & 3;        // (t - 5) mod 4
-            const auto fetch = [&](auto rr) {
-                constexpr int R = decltype(rr)::value;
-                if constexpr (R < kReads) bq[R] = readFrag(rr);
-            };
-            // K-step k = filter tap k of the conv4 / conv5 chain; the first takes the bias as its C operand
+            // ================= matrix phase =================
+            if constexpr ((EXP & 2) == 0) __builtin_amdgcn_s_setprio(1);
+            f16x8 w6r[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) w6r[j] = *reinterpret_cast<const f16x8*>(smemAll + w6Lane[rho] + j * 1024);
+            // K-step k = filter tap k = (i, j) of the conv4 / conv5 chain on input row rc-1+i; the first takes the
+            // bias as its C operand
             const auto body = [&](auto kk) {
                 constexpr int K = decltype(kk)::value;
-                fetch(IC<2 * K + kAhead>{});
-                fetch(IC<2 * K + kAhead + 1>{});
+                constexpr int i = K / 3, j = K % 3, S = (PH + 3 + i) & 3;
+                const f16x8 b0 = fr[S][j * 2], b1 = fr[S][j * 2 + 1];
                 if constexpr (K == 0)
                 {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], bq[0], biasLo, 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], bq[0], biasHi, 0, 0, 0);
-                    piece(IC<0>{});
-                    if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], bq[1], biasLo, 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], bq[1], biasHi, 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], b0, biasLo, 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], b0, biasHi, 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[0], b1, biasLo, 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[1], b1, biasHi, 0, 0, 0);
                 }
                 else
                 {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], bq[2 * K], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], bq[2 * K], acc[1], 0, 0, 0);
-                    piece(IC<2 * K>{});
-                    if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], bq[2 * K + 1], acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], bq[2 * K + 1], acc[3], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], b0, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K], b1, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], b1, acc[3], 0, 0, 0);
                 }
-                piece(IC<2 * K + 1>{});
-                if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             };
-            fetch(IC<0>{}); fetch(IC<1>{}); fetch(IC<2>{}); fetch(IC<3>{});
-            if ((EXP & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{});
             body(IC<5>{}); body(IC<6>{}); body(IC<7>{}); body(IC<8>{});
-            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 0], bq[18], acc6, 0, 0, 0);
-            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 1], bq[19], acc6, 0, 0, 0);
-            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6[rho * 3 + 2], bq[20], acc6, 0, 0, 0);
-
-            // ---- park row t+2
-            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOff) = park;
-            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow32 + ldOffX) = parkX;
-            barrierLds();
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[0], b6[0], acc6, 0, 0, 0);
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[1], b6[1], acc6, 0, 0, 0);
+            acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[2], b6[2], acc6, 0, 0, 0);
+            if constexpr ((EXP & 2) == 0) __builtin_amdgcn_s_setprio(0);
+            lap(5);
+            phaseBarrier();
+            lap(6);
         };
 
-        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX,
-                              const f32x4 (&accPrev)[4], f32x4 (&acc)[4]) {
-            const int rowDone = t - 1 - lag;
-            if (colsAllInside && rowDone >= 0 && rowDone < p.height2)
-                stepImpl(phase, IC<0>{}, t, park, parkX, load, loadX, accPrev, acc);
-            else
-                stepImpl(phase, IC<1>{}, t, park, parkX, load, loadX, accPrev, acc);
-        };
-
-        // steps t0 .. tLast + 3; the three steps after the last store touch only ring rows nothing
-        // reads and store nothing
-        for (int t = t0; t <= tLast; t += 4)
+        // Group 1 runs one phase behind group 0: its load phases coincide with group 0's matrix phases.
+        if (G == 1) phaseBarrier();
+        int t = t0;
+        for (int it = 0; it < iters; ++it, t += 4)
         {
-            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX, accA, accB);
-            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX, accB, accA);
-            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX, accA, accB);
-            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX, accB, accA);
+            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX);
+            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX);
+            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX);
+            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX);
         }
+        if (G == 0) phaseBarrier();
+        if constexpr ((EXP & 4) != 0)
+            if (p.clock && lane == 0 && blockIdx.x < 16)
+                for (int k = 0; k < 8; ++k) p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = spent[k];
     }
     if (p.clock && tid == 0)
     {
@@ -408,8 +433,8 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     StripPlan pl;
     if (width2 <= 0 || height2 <= 0 || batch <= 0 || numCUs <= 0) return pl;
     pl.strips = (width2 + kHrStrip - 1) / kHrStrip;
-    // Rows are cut into segments where that fills the CUs better (two workgroups share a CU): every
-    // segment re-computes 16 warm-up rows, so segments are at least 32 rows tall, and they start at
+    // Rows are cut into segments where that fills the CUs better (a workgroup takes two items, one per CU):
+    // every segment re-computes 16 warm-up rows, so segments are at least 32 rows tall, and they start at
     // multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
     const int maxSegs = height2 / 32 > 1 ? (height2 / 32 < 64 ? height2 / 32 : 64) : 1;
     long bestCost = 0;
@@ -420,11 +445,10 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
         c.segs = (height2 + c.segRows - 1) / c.segRows;
         c.items = c.strips * c.segs * batch;
         c.steps = c.segRows + 16;
-        const int slots = gridFor(c.items, numCUs);
-        c.rounds = (c.items + slots - 1) / slots;
-        // a workgroup that has its CU to itself takes about 0.72 of the time of one of a pair
-        const int last = c.items - (c.rounds - 1) * slots;
-        c.cost = (100L * (c.rounds - 1) + (2 * last <= slots ? 72 : 100)) * c.steps;
+        const int pairs = (c.items + 1) / 2;
+        const int slots = gridFor(pairs, numCUs, 1);
+        c.rounds = (pairs + slots - 1) / slots;
+        c.cost = 100L * c.rounds * c.steps;
         if (segs == 1 || c.cost < bestCost)
         {
             bestCost = c.cost;
@@ -467,7 +491,7 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
 
     const char* env = getenv("SRX_EXP");
     const int exp = env ? atoi(env) : 0;
-    const dim3 grid(gridFor(p.numItems, numCUs)), block(kThreads);
+    const dim3 grid(gridFor((p.numItems + 1) / 2, numCUs, 1)), block(kHrThreads);
 #define SRX_HR_CASE(E)                                                                                       \
     case E: {                                                                                                \
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<E>), kHrSmem);     \
@@ -479,12 +503,12 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.clock = probe ? probe->dev : nullptr;
     switch (exp)
     {
-        SRX_HR_CASE(1) SRX_HR_CASE(2)
+        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(3) SRX_HR_CASE(4)
     default:
         SRX_HR_CASE(0)
     }
 #undef SRX_HR_CASE
-    clockProbeReport(probe, "HrFusedKernel", int(grid.x), s);
+    clockProbeReport(probe, "HrFusedKernel", int(grid.x), s, exp == 4 ? 1024 : 0);
     return hipGetLastError();
 }
 

@@ -362,7 +362,7 @@ hipError_t ensureDynamicLds(const void* kernel, int bytes)
     return r;
 }
 
-void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStream_t s)
+void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStream_t s, int extraWords)
 {
     if (!probePtr) return;
     ClockProbe& probe = *probePtr;
@@ -371,8 +371,18 @@ void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStr
         if (++probe.launches != 40) return;
     }
     if (hipStreamSynchronize(s) != hipSuccess) return;
-    std::vector<unsigned long long> host(2 * size_t(blocks));
-    if (hipMemcpy(host.data(), probe.dev, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::vector<unsigned long long> host(2 * size_t(blocks) + size_t(extraWords));
+    if (hipMemcpy(host.data(), probe.dev, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+    // extra words: [workgroup 0..15][wave 0..7][8 totals] of a kernel's diagnostic build
+    for (int w = 0; w < 8 && extraWords >= 1024; ++w)
+    {
+        double sum[8] = {};
+        for (int b = 0; b < 16; ++b)
+            for (int k = 0; k < 8; ++k) sum[k] += double(host[2 * size_t(blocks) + (size_t(b) * 8 + w) * 8 + k]) / 16;
+        fprintf(stderr, "[srx] %s wave %d: cycles by section:", name, w);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %.0f", sum[k]);
+        fprintf(stderr, "\n");
+    }
     double sum = 0, cyc = 0, usMin = 1e30, usMax = 0, usSum = 0, ghzMin = 1e30, ghzMax = 0;
     double xcdUs[8] = {};
     for (int b = 0; b < blocks; ++b)
