@@ -63,12 +63,11 @@ constexpr int kHrRowPix = 66;
 constexpr int kHrStride = 96;                         // pixel stride of all three rings: 64 B of channels + 32 B, which makes the
                                                       // 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
 constexpr int kHrRow = kHrRowPix * kHrStride;         // 6336
-constexpr int kHrA4 = 0;                              // per group: three rings of four rows
-constexpr int kHrA5 = 4 * kHrRow;
-constexpr int kHrA6 = 8 * kHrRow;
-constexpr int kHrGroupSmem = 12 * kHrRow;             // 76032
+constexpr int kHrA5 = 0;                              // per group: two rings of four rows (conv4's and conv5's outputs)
+constexpr int kHrA6 = 4 * kHrRow;
+constexpr int kHrGroupSmem = 8 * kHrRow;              // 50688
 constexpr int kHrW6 = 2 * kHrGroupSmem;               // conv6 filter fragments of rho == 0: [tap j][lane][16 B]
-constexpr int kHrSmem = kHrW6 + 3 * 1024;             // 155136
+constexpr int kHrSmem = kHrW6 + 3 * 1024;             // 104448
 
 struct HrParams
 {
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int G = wave >> 2;                      // group = strip of the pair
-    const int w4 = wave & 3, gtid = tid & 255;    // wave and thread within the group
+    const int w4 = wave & 3;                      // wave within the group
     const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates: pixel (or output) within 16, group of 8 channels
     const int L = w4 >> 1, ti = w4 & 1;
     char* const smem = smemAll + G * kHrGroupSmem;
@@ -139,16 +138,14 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     for (int i = tid * 16; i < kHrW6; i += kHrThreads * 16) *reinterpret_cast<uint4*>(smemAll + i) = uint4{0, 0, 0, 0};
     if (tid < 192) reinterpret_cast<uint4*>(smemAll + kHrW6)[tid] = reinterpret_cast<const uint4*>(p.wpk6)[tid];
     // conv6 filter fragment of (rho, tap j) for this lane: row (p16 - 4 rho) & 15 of the rho == 0 fragment
-    int w6Lane[4];
-#pragma unroll
-    for (int rho = 0; rho < 4; ++rho) w6Lane[rho] = kHrW6 + ((((p16 - 4 * rho) & 15) + 16 * q) * 16);
+    const auto w6Lane = [&](int rho) { return kHrW6 + ((((p16 - 4 * rho) & 15) + 16 * q) * 16); };
 
     // Ring slots.  Row r of an item lives in slot (r - t0) & 3, t0 = the item's first step.  With
     // the loop unrolled by four the phase PH = (t - t0) & 3 is a compile-time constant, and so is
     // every slot except for the layer-dependent lag (conv5 trails conv4 by 3 rows = 1 slot): that
     // one rotation is folded into these tables, indexed by a compile-time (PH + offset) & 3.
     const int rot = L ? 1 : 0;                     // (-lag) & 3
-    const int inRing = L ? kHrA5 : kHrA4;
+    const int inRing = kHrA5;                       // conv5's input; conv4 takes its input straight from HBM / L2
     const int outRing = L ? kHrA6 : kHrA5;
     int inSlot[4], outSlot[4];
 #pragma unroll
@@ -162,16 +159,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int inLane = (ti * 32 + p16) * kHrStride + q * 16;
     const int in6Lane = kHrA6 + (w4 * 16 + p16) * kHrStride + q * 16;
     const int outLane = (ti * 32 + p16) * kHrStride + q * 16;
-    // Row loader: 66 pixels x 4 chunks of 16 B; thread t of the group takes chunk t & 3 of a pixel, and every wave
-    // also takes the last 8 chunks (identical bytes to identical addresses: keeps the step branch-free).  Within
-    // four pixels the order is 0, 2, 1, 3: eight consecutive lanes then write eight different 16-byte bank groups.
-    const int ldPixRaw = gtid >> 2;
-    const int ldPix = (ldPixRaw & ~3) | ((ldPixRaw & 1) << 1) | ((ldPixRaw >> 1) & 1);
-    const int ldOff = kHrA4 + ldPix * kHrStride + (gtid & 3) * 16;
-    const int ldPixX = min(64 + (lane >> 2), kHrRowPix - 1);
-    const int ldOffX = kHrA4 + ldPixX * kHrStride + (lane & 3) * 16;
-    const int ldSrc = ldPix * 64 + (gtid & 3) * 16;             // byte offsets within an a4 row
-    const int ldSrcX = ldPixX * 64 + (lane & 3) * 16;
+    // conv4's activation fragments come straight from conv_up1's output in HBM / L2: fragment (tap j, pixel half)
+    // of a row is 16 pixels x 64 B = 1 KiB of consecutive bytes, 16 B per lane.  Byte offset of this lane's part
+    // of fragment (0, 0) within the 66 pixels of the strip's row:
+    const int a4Lane = (ti * 32 + p16) * 64 + q * 16;
     // conv6: lane group q holds the output row y with y mod 4 == q
     bool qIs[4];
 #pragma unroll
@@ -203,13 +194,8 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         const int t0 = Y0 - 2;
 
         const long rowBytes = long(p.a4.pitch) * 64;
-        // the a4 row to fetch next (uniform): one buffer descriptor per row, lanes add their chunk offset
+        // the a4 row to fetch next (uniform): one buffer descriptor per row covering the strip's 66 pixels
         const char* rowPtr = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + (long(X0) - 3) * 32) + (Y0 - 3) * rowBytes;
-        const auto loadRow = [&](int voff) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rowPtr), 0, kHrRowPix * 64, 0x00020000);
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-            return uint4{v[0], v[1], v[2], v[3]};
-        };
 
         // output rows at or beyond Y1 fall outside this descriptor and are dropped
         const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -231,20 +217,6 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         const bool colsAllInside = colFirst >= 0 && colFirst + 31 < p.width2;
 
         __syncthreads();
-        // rows Y0-3 .. Y0-1 go straight to LDS (slots of rows t0-1, t0, t0+1), row Y0 stays in flight
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-        {
-            const int slot = (rr - 1) & 3;       // row t0 - 1 + rr
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow + ldOff) = loadRow(ldSrc);
-            *reinterpret_cast<uint4*>(smem + slot * kHrRow + ldOffX) = loadRow(ldSrcX);
-            rowPtr += rowBytes;
-        }
-        // Rows in flight in registers: step t issues the load of row t+3 into one register set and
-        // parks the other (row t+2, loaded during step t-1), so a load has a whole step to land.
-        uint4 rowA = loadRow(ldSrc), rowB = rowA;
-        uint4 rowAX = loadRow(ldSrcX), rowBX = rowAX;
-        rowPtr += rowBytes;
         unsigned xraw = 0;                        // raw input pixel of the next block to store
         // a 32-pixel x 32-output tile as four 16 x 16 accumulators: index = 2 * pixel half + output half.  One
         // set is enough: a step's load phase converts and stores it before the matrix phase starts it anew.
@@ -255,8 +227,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
         // Activation fragments stay in registers for the three steps that use their row (as filter row 2, 1,
-        // 0): fr[s] holds the row of ring slot s, [tap j * 2 + pixel half]; a step fetches only its newest row.
-        // The two older rows of the first step are fetched here.
+        // 0): fr[s] holds the row of ring slot s, [tap j * 2 + pixel half]; a step fetches only one new row.
+        // conv5 waves read it from the a5 ring in the step that first uses it.  conv4 waves load theirs from
+        // memory one step earlier, into the set that is idle (four sets, three in use), so the load has a
+        // whole step to land.  The rows the first step needs besides are fetched here.
         f16x8 fr[4][6];
         const auto fetchRow = [&](auto set, const char* rowBase) {
             constexpr int S = decltype(set)::value;
@@ -266,12 +240,34 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 for (int half = 0; half < 2; ++half)
                     fr[S][j * 2 + half] = *reinterpret_cast<const f16x8*>(rowBase + (half * 16 + j) * kHrStride);
         };
-        fetchRow(IC<3>{}, smem + inSlot[3] + inLane);
-        fetchRow(IC<0>{}, smem + inSlot[0] + inLane);
+        const auto loadA4Row = [&](auto set) {
+            constexpr int S = decltype(set)::value;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rowPtr), 0, kHrRowPix * 64, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, a4Lane + (half * 16 + j) * 64, 0, 0);
+                    fr[S][j * 2 + half] = __builtin_bit_cast(f16x8, v);
+                }
+        };
+        if (L == 0)
+        {
+            // rows Y0-3, Y0-2, Y0-1 = the three input rows of the first step (t0 = Y0 - 2)
+            loadA4Row(IC<3>{}); rowPtr += rowBytes;
+            loadA4Row(IC<0>{}); rowPtr += rowBytes;
+            loadA4Row(IC<1>{}); rowPtr += rowBytes;
+        }
+        else
+        {
+            fetchRow(IC<3>{}, smem + inSlot[3] + inLane);
+            fetchRow(IC<0>{}, smem + inSlot[0] + inLane);
+        }
 
         unsigned long long spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // One step = load phase, barrier, matrix phase, barrier.  PH = (t - t0) & 3.
-        const auto step = [&](auto phase, const int t, uint4& park, uint4& parkX, uint4& load, uint4& loadX) {
+        const auto step = [&](auto phase, const int t) {
             constexpr int PH = decltype(phase)::value;
             constexpr int rho = (PH + 1) & 3;        // (t - 5) mod 4
 
@@ -293,16 +289,16 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             };
             lap(-1);
             // ================= load phase =================
-            // the step's LDS reads: the newest input row (six fragments) and conv6's three
-            fetchRow(IC<(PH + 1) & 3>{}, in2);
-            f16x8 b6[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) b6[j] = *reinterpret_cast<const f16x8*>(c6 + j * kHrStride);
+            // the step's new input row (six fragments): conv5 reads row rc+1 of the a5 ring for this step, conv4
+            // requests row t+2 of conv_up1's output for the next one (the last needed row is Y1+2: stop advancing
+            // there)
+            if (L == 0)
+            {
+                loadA4Row(IC<(PH + 2) & 3>{});
+                rowPtr += (t + 2 < Y1 + 2) ? rowBytes : 0;
+            }
+            else fetchRow(IC<(PH + 1) & 3>{}, in2);
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-            // global loads: row t+3 (the last needed row is Y1+2: stop advancing there)
-            load = loadRow(ldSrc);
-            loadX = loadRow(ldSrcX);
-            rowPtr += (t + 3 < Y1 + 2) ? rowBytes : 0;
             // the block of rows stored three steps from now starts at row t - 7 (phase 1 only)
             if constexpr (PH == 1)
                 xraw = __builtin_amdgcn_raw_buffer_load_b32(inputRsrc, int(laneX0 + unsigned((t - 7) >> 1) * unsigned(p.inputPitch)), 0, 0);
@@ -359,9 +355,6 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
             }
             lap(2);
-            // park row t+2
-            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow + ldOff) = park;
-            *reinterpret_cast<uint4*>(smem + ((PH + 2) & 3) * kHrRow + ldOffX) = parkX;
             if constexpr ((EXP & 4) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             lap(3);
             phaseBarrier();
@@ -369,9 +362,12 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 
             // ================= matrix phase =================
             if constexpr ((EXP & 2) == 0) __builtin_amdgcn_s_setprio(1);
-            f16x8 w6r[3];
+            // conv6's operands are read here: they are needed after the 36 MFMAs of the main chain
+            f16x8 w6r[3], b6[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) w6r[j] = *reinterpret_cast<const f16x8*>(smemAll + w6Lane[rho] + j * 1024);
+            for (int j = 0; j < 3; ++j) w6r[j] = *reinterpret_cast<const f16x8*>(smemAll + w6Lane(rho) + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b6[j] = *reinterpret_cast<const f16x8*>(c6 + j * kHrStride);
             // K-step k = filter tap k = (i, j) of the conv4 / conv5 chain on input row rc-1+i; the first takes the
             // bias as its C operand
             const auto body = [&](auto kk) {
@@ -409,10 +405,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         int t = t0;
         for (int it = 0; it < iters; ++it, t += 4)
         {
-            step(IC<0>{}, t, rowA, rowAX, rowB, rowBX);
-            step(IC<1>{}, t + 1, rowB, rowBX, rowA, rowAX);
-            step(IC<2>{}, t + 2, rowA, rowAX, rowB, rowBX);
-            step(IC<3>{}, t + 3, rowB, rowBX, rowA, rowAX);
+            step(IC<0>{}, t);
+            step(IC<1>{}, t + 1);
+            step(IC<2>{}, t + 2);
+            step(IC<3>{}, t + 3);
         }
         if (G == 0) phaseBarrier();
         if constexpr ((EXP & 4) != 0)
