@@ -362,12 +362,13 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 
             // ================= matrix phase =================
             if constexpr ((EXP & 2) == 0) __builtin_amdgcn_s_setprio(1);
-            // conv6's operands are read here: they are needed after the 36 MFMAs of the main chain
+            // conv6's operands are read here: they are needed after 24 MFMAs of the main chain
             f16x8 w6r[3], b6[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) w6r[j] = *reinterpret_cast<const f16x8*>(smemAll + w6Lane(rho) + j * 1024);
 #pragma unroll
             for (int j = 0; j < 3; ++j) b6[j] = *reinterpret_cast<const f16x8*>(c6 + j * kHrStride);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             // K-step k = filter tap k = (i, j) of the conv4 / conv5 chain on input row rc-1+i; the first takes the
             // bias as its C operand
             const auto body = [&](auto kk) {
@@ -389,11 +390,15 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                     acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[2 * K + 1], b1, acc[3], 0, 0, 0);
                 }
             };
-            body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{});
-            body(IC<5>{}); body(IC<6>{}); body(IC<7>{}); body(IC<8>{});
+            // conv6's three MFMAs go between the last K-steps: at the very end each would wait for the one before
+            body(IC<0>{}); body(IC<1>{}); body(IC<2>{}); body(IC<3>{}); body(IC<4>{}); body(IC<5>{});
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[0], b6[0], acc6, 0, 0, 0);
+            body(IC<6>{});
             acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[1], b6[1], acc6, 0, 0, 0);
+            body(IC<7>{});
             acc6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w6r[2], b6[2], acc6, 0, 0, 0);
+            body(IC<8>{});
             if constexpr ((EXP & 2) == 0) __builtin_amdgcn_s_setprio(0);
             lap(5);
             phaseBarrier();
