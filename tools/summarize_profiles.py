@@ -39,7 +39,11 @@ def main():
         for (k, counter), v in values.items():
             summary[k][counter] = statistics.median(v)      # per launch of eight 1080p frames
     json.dump(summary, open(os.path.join(dst, prefix + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    import datetime
+    import subprocess
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     traffic = {"frames_per_launch": 8,
+               "_measured": f"profile set {tag}, {datetime.date.today().isoformat()}, tree at or after commit {head}",
                "_note": "HBM bytes per launch (eight 1080p frames): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                         "separate passes over tools/time_stages.py --batch 8, KiB -> bytes, FETCH_SIZE doubled (gfx950 "
                         "tallies the 128-B requests of 16-B-per-lane loads at 64 B)",
