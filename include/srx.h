@@ -154,7 +154,8 @@ srx_status srx_upscale_frames(srx_ctx* ctx, uint32_t first, uint32_t count, void
  * matter; pointers and pitches must be multiples of 4.  Images whose workspace need,
  * 64 bytes per OUTPUT pixel plus borders, exceeds the static workspace are refused
  * with SRX_ERR_INVALID (640x360 fits, 1280x720 does not): use srx_upscale for those.
- * All calls on one GPU share that GPU's workspace: calls that overlap in time on one
+ * The call may be captured into a HIP graph (the workspace is cleared by a kernel,
+ * not a memset node).  All calls on one GPU share that GPU's workspace: calls that overlap in time on one
  * GPU, from any ctx, thread or stream, race on it -- order them on one stream.
  * Asynchronous on `stream`.
  */

@@ -724,8 +724,9 @@ srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* 
 
     // The workspace keeps what the previous call left.  Its border, the padding to whole tiles and the slack
     // to the right must read as zeros (they are the zero padding of conv4), and their position depends on
-    // the image size: clear the part this call uses.
-    SRX_HIP(hipMemsetAsync(c->staticScratch, 0, lay.bytes, st));
+    // the image size: clear the part this call uses (with a kernel, not hipMemsetAsync: replayed from a HIP graph,
+    // the memset was seen to run beside the kernel that follows it).
+    SRX_HIP(srx::LaunchZero(c->staticScratch, lay.bytes, st));
 
     const TensorInfo& ti = kTensorInfo[SRX_T_CONV_UP1];
     srx::Tensor a4;

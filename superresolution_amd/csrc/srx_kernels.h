@@ -85,8 +85,8 @@ struct LrFusedLaunch
 };
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s);
 
-// Load the two fused kernels on the current device and raise their shared-memory limits (otherwise done
-// by the first launch on that device).
+// Load the two fused kernels and the zero-fill kernel on the current device and raise the shared-memory limits
+// (otherwise done by the first launch on that device).
 hipError_t PrepareFusedKernels();
 
 // How a fused kernel cuts `batch` frames into work items: strips of columns x segments of rows.
@@ -99,6 +99,11 @@ struct StripPlan
 };
 StripPlan PlanLrFused(int width, int height, int batch, int numCUs);
 StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
+
+// Zero `bytes` bytes at `p` (both multiples of 16) with a plain kernel.  Unlike a memset node, a kernel node keeps
+// its place in a captured stream: inside a HIP graph a hipMemsetAsync of the workspace was seen to overlap the
+// kernel that follows it.
+hipError_t LaunchZero(void* p, size_t bytes, hipStream_t s);
 
 // Channel repacking for the frame pipe's RGB8 mode (tightly packed RGB frames <-> RGBA8 image frames).
 hipError_t LaunchRgbToRgba(const uint8_t* rgb, const Image& dst, int width, int height, int batch, hipStream_t s);

@@ -18,6 +18,7 @@
 // CSImageToTensor / PSTensorToImage shaders (Content/Shaders/*.hlsl).
 #include "srx_device.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -476,6 +477,30 @@ __global__ void RgbaToRgbKernel(const uint8_t* rgba, long pitch, long frame, uin
 }
 
 }  // namespace
+
+namespace {
+__global__ void ZeroKernel(uint4* p, size_t count)
+{
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x)
+        p[i] = uint4{0, 0, 0, 0};
+}
+}  // namespace
+
+hipError_t PrepareZero()
+{
+    hipFuncAttributes attr;      // asking for them loads the kernel on the current device
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(ZeroKernel));
+}
+
+hipError_t LaunchZero(void* p, size_t bytes, hipStream_t s)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0 || (bytes & 15) != 0) return hipErrorInvalidValue;
+    const size_t count = bytes / 16;
+    if (count == 0) return hipSuccess;
+    const int blocks = int(std::min<size_t>((count + 255) / 256, 4096));
+    hipLaunchKernelGGL(ZeroKernel, dim3(blocks), dim3(256), 0, s, static_cast<uint4*>(p), count);
+    return hipGetLastError();
+}
 
 hipError_t LaunchRgbToRgba(const uint8_t* rgb, const Image& dst, int width, int height, int batch, hipStream_t s)
 {

@@ -597,11 +597,13 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
 }
 
 hipError_t PrepareHrFused();
+hipError_t PrepareZero();
 
 hipError_t PrepareFusedKernels()
 {
-    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0>), kLrSmem);
-    return e != hipSuccess ? e : PrepareHrFused();
+    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0>), kLrSmem);
+    if (e == hipSuccess) e = PrepareHrFused();
+    return e != hipSuccess ? e : PrepareZero();
 }
 
 hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)

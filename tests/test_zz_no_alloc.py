@@ -75,3 +75,27 @@ def test_static_workspace_largest_size():
             ctx.upscale_static(src.data_ptr(), w * 4, dst.data_ptr(), 2 * w * 4, w, h, None)
         torch.cuda.synchronize()
         assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+def test_static_entry_point_under_hip_graph_capture():
+    """What the entry point is for: under stream capture nothing can be allocated.  The call is captured into a
+    HIP graph (through torch's wrapper of hipGraph) and replayed twice, the second time on new input bytes; both
+    replays must give the bytes srx_upscale gives.  (A graph whose workspace was cleared by a memset node instead
+    of a kernel node fails the second replay: the memset overlaps the first kernel.)"""
+    import torch
+    w, h = 150, 101
+    frames = [synthetic_rgba(w, h, 7900 + i) for i in range(2)]
+    want = [_reference(f) for f in frames]
+    with S.SuperResolutionContext(16, 16) as ctx:
+        src = torch.from_numpy(frames[0]).cuda()
+        dst = torch.zeros((2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ctx.upscale_static(src.data_ptr(), w * 4, dst.data_ptr(), 2 * w * 4, w, h, side.cuda_stream)
+        for f, ref in zip(frames, want):
+            src.copy_(torch.from_numpy(f).cuda())
+            dst.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy(), ref)
