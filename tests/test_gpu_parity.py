@@ -622,3 +622,28 @@ def test_two_contexts_on_two_host_threads():
     for k in range(2):
         for a, b in zip(got[k], want[k]):
             assert np.array_equal(a, b)
+
+
+def test_upscale_can_be_captured_into_a_hip_graph():
+    """srx_upscale launches kernels only (its set-up was done by srx_create), so a caller may capture it into a
+    HIP graph, here through torch's wrapper, and replay it on new input bytes."""
+    import torch
+    w, h, batch = 131, 77, 3
+    sets = [[synthetic_rgba(w, h, 9300 + 10 * k + i) for i in range(batch)] for k in range(2)]
+    with S.SuperResolutionContext(w, h) as one:
+        want = [[one.run(f) for f in fs] for fs in sets]
+    with S.SuperResolutionContext(w, h, batch=batch) as ctx:
+        side = torch.cuda.Stream()
+        for i, f in enumerate(sets[0]):
+            ctx.upload_rgba8(i, f)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ctx.upscale(side.cuda_stream)
+        for k in range(2):
+            for i, f in enumerate(sets[k]):
+                ctx.upload_rgba8(i, f)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            for i in range(batch):
+                assert np.array_equal(ctx.tensor_to_image(i), want[k][i]), (k, i)
