@@ -1,24 +1,29 @@
 // gfx950 kernel: conv4 -> conv5 -> conv6 -> + NN2x(input) -> UNORM8, fused.
 //
-// A workgroup of eight waves (one per CU, 152 KB LDS) walks TWO strips of kHrStrip output columns
+// A workgroup of eight waves (one per CU, 102 KB LDS) walks TWO strips of kHrStrip output columns
 // downwards, one row per step: waves 0-3 (group 0) own one strip, waves 4-7 (group 1) the next, each
-// with rolling windows of conv_up1's output and of the two intermediate activations in its own LDS
-// rings, so neither intermediate touches HBM and no row is computed twice vertically.  Wave w of a
-// group accumulates, per step, its 32-pixel half (w & 1) of one row of conv4 (w < 2) or conv5
-// (w >= 2) as four 16 x 16 accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap:
-// all 32 input channels), and its 16-pixel quarter of conv6 with 3 more: every wave issues the same
-// work.
+// with rolling windows of the two intermediate activations in its own LDS rings, so neither
+// intermediate touches HBM and no row is computed twice vertically.  Wave w of a group accumulates,
+// per step, its 32-pixel half (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) as four 16 x 16
+// accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap: all 32 input channels),
+// and its 16-pixel quarter of conv6 with 3 more: every wave issues the same matrix work.
 //
-// The two groups alternate.  A step of a group has a LOAD phase (the first twelve activation
-// fragments of the step are fetched from LDS, the previous step's accumulators are converted and
-// stored to the rings, finished conv6 rows are converted and written to the image, the next
-// conv_up1 row is parked in LDS and the one after it requested from HBM) and a MATRIX phase (the 39
-// MFMAs, with the remaining fragment reads running ahead of them).  Waves w and w + 4 share a SIMD
-// and its one matrix pipe; group 1 runs half a step behind group 0, so while one wave of a SIMD
-// streams MFMAs its partner does its vector, LDS-store and memory work, and the other way round
-// after the next barrier (one workgroup barrier per phase).  The matrix pipe then idles only for
-// the barrier itself, not for LDS latency or epilogues, and the two strips of a CU advance in lock
-// step instead of one workgroup starving the other.
+// Activation fragments live in registers for the three steps that use their row (as filter row 2,
+// then 1, then 0), so a step fetches ONE new input row, six fragments of 1 KiB, instead of three.
+// conv5 waves read theirs from the a5 ring in LDS.  conv4 waves take theirs straight from conv_up1's
+// output in memory: a fragment (16 pixels x 32 channels) is 1 KiB of consecutive bytes there, 16 B per
+// lane, and the request goes out one step early into the register set that is idle (four sets, three
+// in use), so there is no copy of conv_up1's rows in LDS at all.
+//
+// The two groups alternate.  A step of a group has a LOAD phase (the new row's fragments are
+// requested, the previous step's accumulators are converted and stored to the rings, finished
+// conv6 rows are moved to holding registers and, every fourth step, converted and written to the
+// image) and a MATRIX phase (the 39 MFMAs and the six LDS reads of conv6's operands, nothing else).
+// Waves w and w + 4 share a SIMD and its one matrix pipe; group 1 runs half a step behind group 0,
+// so while one wave of a SIMD streams MFMAs its partner does its vector, LDS-store and memory work,
+// and the other way round after the next barrier (one workgroup barrier per phase).  The matrix pipe
+// then idles only for the barrier itself, not for LDS latency or epilogues, and the two strips of a
+// CU advance in lock step instead of one workgroup starving the other.
 //
 // conv6 (32 -> 3 channels) streams input rows.  The 16 output rows of its MFMA are four
 // groups of (R, G, B, 0); group g accumulates the output row y with y mod 4 == g.  The
@@ -40,7 +45,7 @@
 //   conv6 pixel i   = column X0 + i      (60 of 64 kept), reads a6 index i..i+2
 //   a6 ring index i = column X0 - 1 + i = conv5 pixel i, which reads a5 index i..i+2
 //   a5 ring index i = column X0 - 2 + i = conv4 pixel i, which reads a4 index i..i+2
-//   a4 ring index i = column X0 - 3 + i   (66 pixels loaded per row)
+//   a4 index i      = column X0 - 3 + i   (66 pixels of conv_up1's row, read from memory)
 // Activations outside the true image are written as zeros: that is the zero
 // padding each of the reference's convolutions applies to its own input
 // (Content/SuperResolution.cpp:245-268 via ML::Util::CreateConvolutionLayer); the
