@@ -202,9 +202,10 @@ srx_status srx_packed_weights(const char* weights_path, int32_t layer, uint16_t*
  * registers (they differ from srx_packed_weights where a fused kernel uses
  * another MFMA shape or order): conv1 as ten K-steps by filter row; conv2,
  * conv3, the four conv_up1 phase filters, conv4 and conv5 as
- * v_mfma_f32_16x16x32_f16 fragments [tile][kstep][output half][lane][8] (conv4
- * and conv5 with the rows of the two halves interleaved: row r of half h is output
- * 8 * (r >> 2) + 4 * h + (r & 3)); conv6 as row-streaming fragments
+ * v_mfma_f32_16x16x32_f16 fragments [tile][kstep][output half][lane][8] (the
+ * rows of the two halves are interleaved: row r of half h is output
+ * 8 * (r >> 2) + 4 * h + (r & 3) of the tile, so that a lane's accumulators of
+ * both halves are eight consecutive channels); conv6 as row-streaming fragments
  * [row mod 4][tap j][lane][8]. */
 srx_status srx_fused_weights(const char* weights_path, int32_t layer, uint16_t* packed_out,
                              size_t cap, size_t* n);

@@ -215,7 +215,7 @@ srx_status uploadWeights(srx_ctx* c)
     {
         const uint32_t* sz = kConvLayers[l].sizes;
         const std::vector<uint16_t> packed = l == 3 ? PackConvUp1PhasesK32(c->folded.filter[l])
-                                                    : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]), l >= 4);
+                                                    : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]), true);
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
@@ -916,7 +916,7 @@ srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, siz
     const std::vector<uint16_t> packed =
         layer == 0 ? srx::PackConv1Rows8(folded.filter[0])
         : layer == 3 ? srx::PackConvUp1PhasesK32(folded.filter[3])
-        : layer <= 5 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]), layer >= 4)
+        : layer <= 5 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]), true)
                      : srx::PackConv6Rotating(folded.filter[6]);
     if (n) *n = packed.size();
     if (out)

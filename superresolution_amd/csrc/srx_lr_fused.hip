@@ -116,12 +116,14 @@ __device__ __forceinline__ f16x4 reluHalf4(const f32x4& acc)
 }
 
 // Initial accumulators of a 32-pixel x 32-output tile held as four 16 x 16 tiles (index = 2 * pixel
-// half + output half): lane group q holds outputs 4q .. 4q+3 of an output half.
+// half + output half).  The MFMA rows of the two output halves are interleaved in the filter fragments
+// (PackConv3x3K32 with `interleave`): lane group q holds outputs 8q .. 8q+3 in the first half's accumulator
+// and 8q+4 .. 8q+7 in the second's, i.e. 8 consecutive channels of a pixel = one 16-byte store.
 __device__ __forceinline__ void biasAcc16(const char* smem, int tableOff, int q, f32x4 (&acc)[4])
 {
-    const float* t = reinterpret_cast<const float*>(smem) + tableOff + 4 * q;
+    const float* t = reinterpret_cast<const float*>(smem) + tableOff + 8 * q;
     acc[0] = acc[2] = *reinterpret_cast<const f32x4*>(t);
-    acc[1] = acc[3] = *reinterpret_cast<const f32x4*>(t + 16);
+    acc[1] = acc[3] = *reinterpret_cast<const f32x4*>(t + 4);
 }
 
 // The first kAhead activation fragments of a chain, fetched while the chain before it runs.
@@ -275,21 +277,19 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // to finish the last tile
             const int py = wave >> 1, pxp = wave & 1;
             const int laneRd = kA3Off + p16 * kA2Stride + q * 16;      // + pixel and tap offsets
-            // A lane ends up with 8 consecutive channels of one pixel (16 B of an a4 row): channels
-            // 0-7, 16-23, 8-15, 24-31 for q = 0 .. 3.  Lanes that own no pixel get an offset no buffer
-            // descriptor covers, so their stores are dropped.
+            // A lane holds 8 consecutive channels of one pixel (16 B of an a4 row): channels 8q .. 8q+7.
+            // Lanes that own no pixel get an offset no buffer descriptor covers, so their stores are dropped.
             unsigned laneSt[4];
 #pragma unroll
             for (int T = 0; T < 4; ++T)        // T = 16-pixel quarter of the 64-pixel row
             {
                 const int i = T * 16 + p16, col = X0 + i;
                 laneSt[T] = (i < kLrStrip && col < p.width)
-                                ? unsigned((2 * col + pxp) * 64 + ((q & 1) * 32 + (q >> 1) * 16)) : 0xC0000000u;
+                                ? unsigned((2 * col + pxp) * 64 + q * 16) : 0xC0000000u;
             }
             const long rowBytes = long(p.a4.pitch) * 64;
             char* a4f = reinterpret_cast<char*>(p.a4.base + f * p.a4.frame);
-            // finish a 32-pixel tile: ReLU, fp16, widen to 8 consecutive channels per lane, one 16-B store per
-            // 16-pixel half
+            // finish a 32-pixel tile: ReLU, fp16, one 16-B store per 16-pixel half
             unsigned d[4];
             const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32, bool rowValid) {
                 constexpr int K = decltype(kk)::value;
@@ -308,15 +308,6 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 if constexpr (K == 5 || K == 13)
                 {
                     constexpr int half = K == 5 ? 0 : 1;
-                    // rows of 16 lanes: odd rows of the first operand swap with even rows of the second, after
-                    // which a lane holds 8 consecutive channels
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                    {
-                        const auto r = __builtin_amdgcn_permlane16_swap(d[k], d[2 + k], false, false);
-                        d[k] = r[0];
-                        d[2 + k] = r[1];
-                    }
                     // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                         a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
@@ -373,25 +364,27 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // step to finish the last tile
             const int nt = wave - 4;
             const int laneRd = kA2Off + p16 * kA2Stride + q * 16;
-            const int laneWr = kA3Off + p16 * kA2Stride + nt * 64 + q * 8;
+            const int laneWr = kA3Off + p16 * kA2Stride + nt * 64 + q * 16;
             bool colInside[4];
 #pragma unroll
             for (int T = 0; T < 4; ++T) colInside[T] = X0 - 1 + T * 16 + p16 >= 0 && X0 - 1 + T * 16 + p16 < p.width;
-            f16x4 v;
-            // accumulator a = (16-pixel half a >> 1, 16-output half a & 1) of the 32 x 32 tile
+            f16x4 vLo, vHi;
+            // accumulator a = (16-pixel half a >> 1, 16-output half a & 1) of the 32 x 32 tile; the two output
+            // halves of a pixel make one 16-byte store
             const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K >= 1 && K <= 13 && (K - 1) % 4 == 0)
+                if constexpr (K == 1 || K == 3 || K == 9 || K == 11)
                 {
-                    constexpr int a = (K - 1) / 4;
+                    constexpr int a = K == 1 ? 0 : (K == 3 ? 1 : (K == 9 ? 2 : 3));
                     const bool inside = colInside[T32 * 2 + (a >> 1)] && row >= 0 && row < p.height;
-                    v = reluHalf4(acc[a]);
-                    v = inside ? v : f16x4{0, 0, 0, 0};
+                    const f16x4 v = reluHalf4(acc[a]);
+                    ((a & 1) ? vHi : vLo) = inside ? v : f16x4{0, 0, 0, 0};
                 }
-                if constexpr (K >= 3 && K <= 15 && (K - 3) % 4 == 0)
+                if constexpr (K == 5 || K == 13)
                 {
-                    constexpr int a = (K - 3) / 4;
-                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + (a >> 1) * 16) * kA2Stride + (a & 1) * 32) = v;
+                    constexpr int half = K == 5 ? 0 : 1;
+                    *reinterpret_cast<f16x8*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + half * 16) * kA2Stride) =
+                        __builtin_shufflevector(vLo, vHi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
             };
             const auto rdT = [&](auto rr, int T32, int c0, int c1, int c2) -> f16x8 {
@@ -439,24 +432,25 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // ---- conv2, all 64 outputs as four chains (tile, half of the outputs): row r2 at step r2 + 2,
             // rows Y0-2 .. Y1+1, and one more step to finish the last chain
             const int laneRd = kA1Off + p16 * kA1Stride + q * 16;
-            const int laneWr = kA2Off + p16 * kA2Stride + q * 8;
+            const int laneWr = kA2Off + p16 * kA2Stride + q * 16;
             bool colInside[4];
 #pragma unroll
             for (int T = 0; T < 4; ++T) colInside[T] = X0 - 2 + T * 16 + p16 >= 0 && X0 - 2 + T * 16 + p16 < p.width;
-            f16x4 v;
+            f16x4 vLo, vHi;
             const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32, int oTile) {
                 constexpr int K = decltype(kk)::value;
-                if constexpr (K <= 6 && K % 2 == 0)
+                if constexpr (K == 0 || K == 1 || K == 4 || K == 5)
                 {
-                    constexpr int a = K / 2;
+                    constexpr int a = K == 0 ? 0 : (K == 1 ? 1 : (K == 4 ? 2 : 3));
                     const bool inside = colInside[T32 * 2 + (a >> 1)] && row >= 0 && row < p.height;
-                    v = reluHalf4(acc[a]);
-                    v = inside ? v : f16x4{0, 0, 0, 0};
+                    const f16x4 v = reluHalf4(acc[a]);
+                    ((a & 1) ? vHi : vLo) = inside ? v : f16x4{0, 0, 0, 0};
                 }
-                if constexpr (K <= 7 && K % 2 == 1)
+                if constexpr (K == 2 || K == 6)
                 {
-                    constexpr int a = K / 2;
-                    *reinterpret_cast<f16x4*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + (a >> 1) * 16) * kA2Stride + oTile * 64 + (a & 1) * 32) = v;
+                    constexpr int half = K == 2 ? 0 : 1;
+                    *reinterpret_cast<f16x8*>(smem + laneWr + slot5(row) * kA2Row + (T32 * 32 + half * 16) * kA2Stride + oTile * 64) =
+                        __builtin_shufflevector(vLo, vHi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
             };
             // read r of a chain: K-step r / 2 = tap (32 input channels), 16-pixel half r % 2

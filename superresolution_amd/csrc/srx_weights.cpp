@@ -492,7 +492,7 @@ std::vector<uint16_t> PackConvUp1PhasesK32(const std::vector<uint16_t>& oihw)
     {
         const std::vector<uint16_t> one(phases.begin() + size_t(p) * 32 * 64 * 9,
                                         phases.begin() + size_t(p + 1) * 32 * 64 * 9);
-        const std::vector<uint16_t> packed = PackConv3x3K32(one, 32, 64);
+        const std::vector<uint16_t> packed = PackConv3x3K32(one, 32, 64, true);
         out.insert(out.end(), packed.begin(), packed.end());
     }
     return out;

@@ -154,7 +154,7 @@ std::vector<uint16_t> PackConvUp1Phases(const std::vector<uint16_t>& oihw /*[32,
 // [half: outputs 0-15 / 16-31 of the tile][lane][8]; a K-step covers input channels 32*kc .. 32*kc+31
 // of one tap.  With `interleave`, row r of half h holds output 8 * (r >> 2) + 4 * h + (r & 3) of the tile instead
 // of 16 * h + r: the lane group that gets D rows 4q .. 4q+3 of both halves then owns outputs 8q .. 8q+7.
-// PackConvUp1PhasesK32: the four phase filters of conv_up1, [phase] in front.
+// PackConvUp1PhasesK32: the four phase filters of conv_up1, [phase] in front, interleaved.
 std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout, int cin, bool interleave = false);
 std::vector<uint16_t> PackConvUp1PhasesK32(const std::vector<uint16_t>& oihw /*[32,64,5,5]*/);
 // The phase filters themselves, [4][32][64][3][3] fp16 (for tests).

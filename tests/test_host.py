@@ -137,7 +137,7 @@ def test_packed_up1_phase_filters(oracle):
 
 
 def test_fused_k32_layout():
-    """conv2 / conv3 / conv4 / conv5 as v_mfma_f32_16x16x32_f16 A fragments: lane (r, q) = output r of its half,
+    """conv2 / conv3 / conv4 / conv5 as v_mfma_f32_16x16x32_f16 A fragments: lane (r, q) = row r of its half,
     channels 8q..8q+7."""
     for li, (cout, cin) in {1: (64, 32), 2: (64, 64), 4: (32, 32), 5: (32, 32)}.items():
         f, _ = S.fold_weights(li)
@@ -148,9 +148,9 @@ def test_fused_k32_layout():
             r, q = lane & 15, lane >> 4
             for tile in range(cout // 32):
                 for half in range(2):
-                    # conv4 / conv5: the rows of the two halves are interleaved, so that a lane group's four D rows of
-                    # both halves are eight consecutive outputs
-                    o = tile * 32 + (8 * (r >> 2) + 4 * half + (r & 3) if li >= 4 else half * 16 + r)
+                    # the rows of the two halves are interleaved, so that a lane group's four D rows of both halves
+                    # are eight consecutive outputs
+                    o = tile * 32 + 8 * (r >> 2) + 4 * half + (r & 3)
                     for kc in range(kch):
                         want = w[o, kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :]           # [8, 9]
                         got = p[tile, kc::kch, half, lane, :]                             # [9 taps, 8]
@@ -159,7 +159,7 @@ def test_fused_k32_layout():
 
 def test_fused_up1_phases_k32_match_the_32x32_packing():
     """The four phase filters, once as 32x32x16 fragments (layer-wise kernel) and once as 16x16x32
-    fragments (fused kernel), hold the same numbers."""
+    fragments (fused kernel, rows of the two output halves interleaved), hold the same numbers."""
     a = S.packed_weights(3).reshape(4, -1)
     b = S.fused_weights(3).reshape(4, 18, 2, 64, 8)
     for ph in range(4):
@@ -168,7 +168,7 @@ def test_fused_up1_phases_k32_match_the_32x32_packing():
             r, q = lane & 15, lane >> 4
             for half in range(2):
                 for kc in range(2):
-                    assert np.array_equal(b[ph, kc::2, half, lane, :], w[half * 16 + r, kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :].T)
+                    assert np.array_equal(b[ph, kc::2, half, lane, :], w[8 * (r >> 2) + 4 * half + (r & 3), kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :].T)
 
 
 def test_fused_conv6_rotating_layout():
