@@ -187,7 +187,8 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
 }
 
 // EXP (diagnostic build variants, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
-// epilogue pieces itself.
+// epilogue pieces itself; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave
+// waits at the step barrier.
 template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
@@ -227,11 +228,29 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     __syncthreads();
     if (tid < 192) reinterpret_cast<float*>(smem)[tid] = p.bias[tid];
 
-    const auto stepBarrier = [] { barrierLds(); };
+    // EXP & 4 (with SRX_CLOCK): cycles each wave of the first 16 workgroups spends at the step barrier
+    unsigned long long waited = 0;
+    const auto stepBarrier = [&] {
+        if constexpr ((EXP & 4) != 0)
+        {
+            const unsigned long long a = __builtin_amdgcn_s_memtime();
+            barrierLds();
+            waited += __builtin_amdgcn_s_memtime() - a;
+        }
+        else barrierLds();
+    };
     // The conv_up1 waves write nothing to LDS, and the LDS reads they have in flight at the end of a step are
     // the first fragments of the NEXT step (rows no wave overwrites during it): their barrier need not wait
     // for LDS at all, so that latency passes while the wave waits for the others (0.5 % of the kernel).
-    const auto stepBarrierReader = [] { asm volatile("s_barrier" ::: "memory"); };
+    const auto stepBarrierReader = [&] {
+        if constexpr ((EXP & 4) != 0)
+        {
+            const unsigned long long a = __builtin_amdgcn_s_memtime();
+            asm volatile("s_barrier" ::: "memory");
+            waited += __builtin_amdgcn_s_memtime() - a;
+        }
+        else asm volatile("s_barrier" ::: "memory");
+    };
 
     const int perFrame = p.strips * p.segs;
     for (TileWalk tw(p.numItems); tw.valid(); tw.next())
@@ -557,6 +576,9 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             }
         }
     }
+    if constexpr ((EXP & 4) != 0)
+        if (p.clock && lane == 0 && blockIdx.x < 16)
+            for (int k = 0; k < 8; ++k) p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = k == 6 ? waited : 0;
     if (p.clock && tid == 0)
     {
         p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
@@ -643,12 +665,12 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     }
     switch (exp)
     {
-        SRX_LR_CASE(1)
+        SRX_LR_CASE(1) SRX_LR_CASE(4)
     default:
         SRX_LR_CASE(0)
     }
 #undef SRX_LR_CASE
-    clockProbeReport(probe, "LrFusedKernel", int(grid.x), s);
+    clockProbeReport(probe, "LrFusedKernel", int(grid.x), s, (exp & 4) ? 1024 : 0);
     return hipGetLastError();
 }
 
