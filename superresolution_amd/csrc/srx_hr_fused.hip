@@ -88,6 +88,17 @@ struct HrParams
     unsigned long long* clock;       // diagnostic (see ClockProbe), usually nullptr
 };
 
+// The barrier between a group's load phase and its matrix phase only keeps the two groups in step: what a load
+// phase stores to LDS is first read after the NEXT barrier (phaseBarrier, which waits for LDS), and what it reads
+// from LDS the matrix phase waits for where it uses it.  So this one does not wait for LDS: the stores drain and
+// the reads land while the MFMAs run.
+__device__ __forceinline__ void phaseBarrierNoWait()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int N>
 using IC = std::integral_constant<int, N>;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -309,26 +320,26 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 xraw = __builtin_amdgcn_raw_buffer_load_b32(inputRsrc, int(laneX0 + unsigned((t - 7) >> 1) * unsigned(p.inputPitch)), 0, 0);
             lap(0);
 
-            // the previous step's epilogue.  MASKED = 0: every value this wave finishes lies inside the image (the
-            // common case), so the zeroing of out-of-image activations is compiled out.
+            // the previous step's epilogue: ReLU, fp16, one 16-byte store per 16-pixel half
             const int rowDone = t - 1 - lag;                         // conv4 / conv5 row being finished
             const bool rowInside = rowDone >= 0 && rowDone < p.height2;
-            const auto epilogue = [&](auto masked) {
-                constexpr bool MASKED = decltype(masked)::value != 0;
+            // accumulator a of the finished row: outputs 8q + 4 * (a & 1) .. + 3 of pixel 16 * (a >> 1) + p16
+            f16x4 fin[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                fin[a] = __builtin_elementwise_max(to_half4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]), f16x4{0, 0, 0, 0});
+            // Activations outside the image are zeros.  In the common case every value this wave finishes lies
+            // inside: the zeroing sits behind a wave-uniform branch (the empty asm keeps the compiler from turning
+            // it into eight selects that always run).
+            if (!(colsAllInside && rowInside))
+            {
+                asm volatile("" ::: "memory");
                 const bool inside0 = rowInside & colInside0, inside1 = rowInside & colInside1;
-                // accumulator a of the finished row: outputs 8q + 4 * (a & 1) .. + 3 of pixel 16 * (a >> 1) + p16
-                const auto reluHalf4 = [&](int a) {
-                    f16x4 v = to_half4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
-                    v = __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
-                    if constexpr (!MASKED) return v;
-                    return ((a >> 1) ? inside1 : inside0) ? v : f16x4{0, 0, 0, 0};
-                };
-                *reinterpret_cast<f16x8*>(outDst) = __builtin_shufflevector(reluHalf4(0), reluHalf4(1), 0, 1, 2, 3, 4, 5, 6, 7);
-                *reinterpret_cast<f16x8*>(outDst + 16 * kHrStride) =
-                    __builtin_shufflevector(reluHalf4(2), reluHalf4(3), 0, 1, 2, 3, 4, 5, 6, 7);
-            };
-            if (colsAllInside && rowInside) epilogue(IC<0>{});
-            else epilogue(IC<1>{});
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fin[a] = ((a >> 1) ? inside1 : inside0) ? fin[a] : f16x4{0, 0, 0, 0};
+            }
+            *reinterpret_cast<f16x8*>(outDst) = __builtin_shufflevector(fin[0], fin[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<f16x8*>(outDst + 16 * kHrStride) = __builtin_shufflevector(fin[2], fin[3], 0, 1, 2, 3, 4, 5, 6, 7);
             lap(1);
 
             // conv6: the output row t-7 was finished by the last matrix phase; its group is (PH + 3) & 3
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             lap(2);
             if constexpr ((EXP & 4) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             lap(3);
-            phaseBarrier();
+            phaseBarrierNoWait();
             lap(4);
 
             // ================= matrix phase =================
