@@ -181,8 +181,13 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int a4Lane = (ti * 32 + p16) * 64 + q * 16;
     // conv6: lane group q holds the output row y with y mod 4 == q
     bool qIs[4];
+    unsigned long long qMask[4];                  // the same as lane masks, for the in-place selects below
 #pragma unroll
-    for (int g = 0; g < 4; ++g) qIs[g] = q == g;
+    for (int g = 0; g < 4; ++g)
+    {
+        qIs[g] = q == g;
+        qMask[g] = __builtin_amdgcn_ballot_w64(q == g);
+    }
 
     const int perFrame = p.strips * p.segs;
     // iterations of four steps an item takes: steps t0 = Y0 - 2 .. tLast + 3, tLast = the step that stores the last
@@ -345,12 +350,15 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             // conv6: the output row t-7 was finished by the last matrix phase; its group is (PH + 3) & 3
             {
                 constexpr int g = (PH + 3) & 3;
-                hold0 = qIs[g] ? acc6[0] : hold0;
-                hold1 = qIs[g] ? acc6[1] : hold1;
-                hold2 = qIs[g] ? acc6[2] : hold2;
-                acc6[0] = qIs[g] ? 0.0f : acc6[0];
-                acc6[1] = qIs[g] ? 0.0f : acc6[1];
-                acc6[2] = qIs[g] ? 0.0f : acc6[2];
+                // Taken and cleared in place, here: written as C++ selects, the compiler postpones the taking to
+                // the step that converts the block, keeps the old accumulator alive for it and moves the
+                // accumulator to other registers every step (three more copies).
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold0) : "v"(acc6[0]), "s"(qMask[g]));
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold1) : "v"(acc6[1]), "s"(qMask[g]));
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold2) : "v"(acc6[2]), "s"(qMask[g]));
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(acc6[k]) : "s"(qMask[g]));
             }
             // every fourth step: the block of rows t-10 .. t-7 is complete in the holding registers;
             // lane (p16, q) converts and stores pixel (row t-10+q, column col6)
