@@ -21,9 +21,12 @@
 // image) and a MATRIX phase (the 39 MFMAs and the six LDS reads of conv6's operands, nothing else).
 // Waves w and w + 4 share a SIMD and its one matrix pipe; group 1 runs half a step behind group 0,
 // so while one wave of a SIMD streams MFMAs its partner does its vector, LDS-store and memory work,
-// and the other way round after the next barrier (one workgroup barrier per phase).  The matrix pipe
-// then idles only for the barrier itself, not for LDS latency or epilogues, and the two strips of a
-// CU advance in lock step instead of one workgroup starving the other.
+// and the other way round after the next barrier (one workgroup barrier per phase; the one that ends a
+// load phase does not wait for LDS, see phaseBarrierNoWait).  The matrix pipe then idles only for the
+// barrier itself, not for LDS latency or epilogues, and the two strips of a CU advance in lock step
+// instead of one workgroup starving the other.  A wave in its matrix phase issues nothing but MFMAs, so
+// every vector instruction of its partner's load phase takes an issue slot from that stream: the load
+// phase is kept as short in instructions as it can be.
 //
 // conv6 (32 -> 3 channels) streams input rows.  The 16 output rows of its MFMA are four
 // groups of (R, G, B, 0); group g accumulates the output row y with y mod 4 == g.  The
