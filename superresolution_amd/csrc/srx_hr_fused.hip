@@ -178,6 +178,15 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int inLane = (ti * 32 + p16) * kHrStride + q * 16;
     const int in6Lane = kHrA6 + (w4 * 16 + p16) * kHrStride + q * 16;
     const int outLane = (ti * 32 + p16) * kHrStride + q * 16;
+    // this lane's store address in each slot of the output ring, kept in registers (made opaque: the compiler
+    // would otherwise keep the lane part and add the slot in every step, one more vector instruction)
+    int outAddr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        outAddr[k] = G * kHrGroupSmem + outSlot[k] + outLane;
+        asm volatile("" : "+v"(outAddr[k]));
+    }
     // conv4's activation fragments come straight from conv_up1's output in HBM / L2: fragment (tap j, pixel half)
     // of a row is 16 pixels x 64 B = 1 KiB of consecutive bytes, 16 B per lane.  Byte offset of this lane's part
     // of fragment (0, 0) within the 66 pixels of the strip's row:
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             // ---- LDS addresses of this step
             const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;        // the newest row (rc+1) of the input ring
             const char* c6 = smem + ((PH + 3) & 3) * kHrRow + in6Lane;     // row t-5 of a6
-            char* outDst = smem + outSlot[(PH + 3) & 3] + outLane;         // row rc-1 of the output ring
+            char* outDst = smemAll + outAddr[(PH + 3) & 3];               // row rc-1 of the output ring
 
             unsigned long long stamp = 0;
             const auto lap = [&](int k) {
