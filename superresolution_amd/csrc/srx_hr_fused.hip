@@ -362,15 +362,15 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             // conv6: the output row t-7 was finished by the last matrix phase; its group is (PH + 3) & 3
             {
                 constexpr int g = (PH + 3) & 3;
-                // Taken and cleared in place, here: written as C++ selects, the compiler postpones the taking to
-                // the step that converts the block, keeps the old accumulator alive for it and moves the
-                // accumulator to other registers every step (three more copies).
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold0) : "v"(acc6[0]), "s"(qMask[g]));
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold1) : "v"(acc6[1]), "s"(qMask[g]));
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(hold2) : "v"(acc6[2]), "s"(qMask[g]));
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(acc6[k]) : "s"(qMask[g]));
+                // Taken and cleared in place with three swaps under the lane mask of group g: the holding
+                // registers of those lanes are zero (cleared after each block store), so the swap moves the
+                // finished row out and zeros into the accumulator.  All lanes are active here (full
+                // workgroup, uniform control flow), so EXEC is restored to all ones.  Written as C++ selects
+                // this is six selects and, because the compiler postpones the taking to the step that converts
+                // the block and keeps the old accumulator alive for it, three register copies per step.
+                asm volatile("s_mov_b64 exec, %6\n\tv_swap_b32 %0, %3\n\tv_swap_b32 %1, %4\n\tv_swap_b32 %2, %5\n\ts_mov_b64 exec, -1"
+                             : "+v"(hold0), "+v"(hold1), "+v"(hold2), "+v"(acc6[0]), "+v"(acc6[1]), "+v"(acc6[2])
+                             : "s"(qMask[g]));
             }
             // every fourth step: the block of rows t-10 .. t-7 is complete in the holding registers;
             // lane (p16, q) converts and stores pixel (row t-10+q, column col6)
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 const bool ok = laneOwns & (blk >= Y0);
                 const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xffffffffu;
                 __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
+                hold0 = hold1 = hold2 = 0.0f;         // what the swaps above put into the accumulator
             }
             lap(2);
             if constexpr ((EXP & 4) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
