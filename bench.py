@@ -368,7 +368,7 @@ def main():
                     tj = json.load(open(tp))
                     traffic = tj.get(dom)
                     traffic_note = ("traffic is NOT measured by this run: it is the HBM byte count per launch from the "
-                                    "committed rocprofv3 --pmc passes (profiles/traffic.json, " + tj.get("_measured", "round 1") + ")")
+                                    "committed rocprofv3 --pmc passes (profiles/traffic.json, " + tj.get("_measured", "date not recorded") + ")")
                 except Exception:
                     traffic = None
             out["roofline"] = {
