@@ -192,14 +192,9 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     // of fragment (0, 0) within the 66 pixels of the strip's row:
     const int a4Lane = (ti * 32 + p16) * 64 + q * 16;
     // conv6: lane group q holds the output row y with y mod 4 == q
-    bool qIs[4];
-    unsigned long long qMask[4];                  // the same as lane masks, for the in-place selects below
+    unsigned long long qMask[4];                  // lane masks of the four groups, for the swaps of the load phase
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-    {
-        qIs[g] = q == g;
-        qMask[g] = __builtin_amdgcn_ballot_w64(q == g);
-    }
+    for (int g = 0; g < 4; ++g) qMask[g] = __builtin_amdgcn_ballot_w64(q == g);
 
     const int perFrame = p.strips * p.segs;
     // iterations of four steps an item takes: steps t0 = Y0 - 2 .. tLast + 3, tLast = the step that stores the last
