@@ -60,7 +60,9 @@ def synthetic_frame(seed, w=W, h=H):
 
 
 def cpu_baseline():
-    """The CPU oracle (reference graph, direct form) timed on this host on a bounded sample."""
+    """The CPU oracle (reference graph, direct form) timed on this host on a bounded sample.
+    Returns the report and what the oracle computed for the whole frame (the 8-bit image and conv_up1's
+    tensor), which parity_block() compares the GPU path with."""
     from oracle import sro
     host_cores = os.cpu_count() or 1
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, host_cores)
@@ -71,8 +73,9 @@ def cpu_baseline():
     frame = synthetic_frame(1080)
     model.run(frame[:64, :64].copy())                      # touch code and pages
     t0 = time.perf_counter()
-    model.run(frame)
+    ref_image = model.run(frame, keep_tensors=True)
     dt = time.perf_counter() - t0
+    ref = {"frame": frame, "image": ref_image, "conv_up1": model.tensor(sro.T_CONV_UP1)}
     out = {"value": round(4 * W * H / 1e6 / dt, 4), "unit": "output megapixels/s", "cores": threads,
            "host_cores": host_cores, "kind": "port",
            "sample": f"one whole synthetic {W}x{H} frame through oracle/sr_oracle.c "
@@ -90,6 +93,42 @@ def cpu_baseline():
                                 "sample": f"512x512 crop of the same frame, one thread, {dt1:.2f} s"}
     except OSError:
         pass
+    return out, ref
+
+
+# the tolerance the path is specified to: 8-bit image within 1 LSB on at least 99.9 % of the pixels,
+# tensors within 2e-2 (fp16 storage, fp32 accumulation in another order than the oracle's running sums)
+PARITY_IMAGE_FRAC, PARITY_TENSOR_TOL = 0.999, 2e-2
+
+
+def parity_block(S, ref, device):
+    """The GPU path on the very frame the cpu_baseline leg pushed through the oracle, in the plan the
+    headline number runs (a pass of eight 1080p frames: first and last slot), against the oracle's
+    whole 3840x2160 image and its conv_up1 tensor (reference graph, direct 5x5 on the upsampled tensor)."""
+    frame = ref["frame"]
+    h, w = frame.shape[:2]
+    with S.SuperResolutionContext(w, h, batch=8, device=device) as ctx:
+        for i in (0, 7):
+            ctx.upload_rgba8(i, frame)
+        ctx.upscale()
+        ctx.sync()
+        images = [ctx.tensor_to_image(i) for i in (0, 7)]
+        a4 = ctx.read_tensor(4, frame=7)
+        plan = ctx.frames_per_launch
+    d = np.abs(images[0][..., :3].astype(np.int16) - ref["image"][..., :3].astype(np.int16))
+    a4_err = 0.0
+    for c0 in range(0, a4.shape[0], 8):                       # in slices: bounds the float32 copies
+        a4_err = max(a4_err, float(np.abs(a4[c0:c0 + 8].astype(np.float32) - ref["conv_up1"][c0:c0 + 8]).max()))
+    out = {"within_1_lsb": round(float((d <= 1).mean()), 6), "identical": round(float((d == 0).mean()), 6),
+           "max_lsb": int(d.max()), "a4_max_abs": round(a4_err, 6),
+           "alpha_255": bool((images[0][..., 3] == 255).all()),
+           "slots_equal": bool(np.array_equal(images[0], images[1])),
+           "tolerance": {"within_1_lsb": PARITY_IMAGE_FRAC, "a4_max_abs": PARITY_TENSOR_TOL},
+           "sample": f"the cpu_baseline frame ({w}x{h}, every one of its {4 * w * h} output pixels and the whole "
+                     f"32-channel conv_up1 tensor) through a pass of {plan} frames, slots 0 and 7, against "
+                     "oracle/sr_oracle.c (direct form)"}
+    out["ok"] = bool(out["within_1_lsb"] >= PARITY_IMAGE_FRAC and out["a4_max_abs"] <= PARITY_TENSOR_TOL
+                     and out["alpha_255"] and out["slots_equal"])
     return out
 
 
@@ -221,11 +260,17 @@ def main():
     if not dry:
         local_rank %= n_dev
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # A process group whenever a launcher started this rank (RANK set), also for one rank: a 1-GPU run
+    # under torch.distributed.run then goes through the very calls of the 8-GPU run.
+    grouped = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    backend = None
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared:      # RCCL refuses two ranks on one GPU; the barrier and the max-reduce then go over gloo
+            backend = "gloo"
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            backend = "nccl"
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from superresolution_amd import sharding
@@ -258,7 +303,7 @@ def main():
         pixels_per_step = sum((t.x1 - t.x0) * (t.y1 - t.y0) for t in mine)   # interiors: halo rows are overhead
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -347,6 +392,7 @@ def main():
                                                            for p, s in zip(per_rank_pixels, per_rank_s)]
             out["tile_check"] = tile_check
         out["per_rank_seconds"] = [round(s, 5) for s in per_rank_s]
+        out["timing_collectives"] = backend        # "nccl" (RCCL), "gloo" (rehearsal) or None (single process, no group)
         if not dry:
             per_gpu = total_pixels * args.steps / elapsed / world      # input pixels per second per GPU
             out["mfma_frac_whole_path"] = round(per_gpu * FLOP_PER_PIXEL / PEAK_FP16_DENSE, 4)
@@ -393,12 +439,22 @@ def main():
                 out["latency_ms_single_frame"] = single_frame_latency(S, distinct[0], local_rank)
             if not args.no_pcie_leg:
                 out["pcie_inclusive"] = pcie_inclusive(S, distinct, local_rank)
+        parity_failed = False
         if not dry and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], ref = cpu_baseline()
+            if args.config == "stream":
+                out["parity"] = parity_block(S, ref, local_rank)
+                parity_failed = not out["parity"]["ok"]
+            del ref
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            print("bench.py: the GPU path is outside its tolerance against the oracle (see \"parity\")", file=sys.stderr)
+            for c in ctxs:
+                c.close()
+            raise SystemExit(3)
     for c in ctxs:
         c.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

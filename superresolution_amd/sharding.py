@@ -90,7 +90,9 @@ def gather_tiles(interiors, width, height, tiles_x, tiles_y, rank, world, dst=0,
             raise ValueError("gather_tiles: interior of tile %r has the wrong shape or type" % (t,))
         flat[pos:pos + a.size] = a.reshape(-1)
         pos += a.size
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        if world != 1:
+            raise RuntimeError("gather_tiles: world > 1 needs an initialised torch.distributed process group")
         parts = [torch.from_numpy(flat)]
     else:
         mine = torch.from_numpy(flat).to(device)
@@ -110,10 +112,12 @@ def gather_tiles(interiors, width, height, tiles_x, tiles_y, rank, world, dst=0,
 
 
 def max_over_ranks(seconds):
-    """Slowest rank's time (what a frame-sharded job takes); identity without a process group."""
+    """Slowest rank's time (what a frame-sharded job takes); identity without a process group.
+    With a process group the reduction runs whatever the world size, so a one-rank job exercises
+    the same calls as an eight-rank one."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return seconds
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=dev)
@@ -125,7 +129,7 @@ def gather_over_ranks(value):
     """Every rank's `value` (a float), in rank order, on every rank; [value] without a process group."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [float(value)]
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     mine = torch.tensor([value], dtype=torch.float64, device=dev)

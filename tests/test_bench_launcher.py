@@ -46,3 +46,22 @@ def test_a_failing_rank_fails_the_run():
     r = run(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"], env={"SRX_BENCH_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_one_rank_under_a_launcher_still_forms_a_process_group():
+    """RANK / WORLD_SIZE=1 / MASTER_PORT in the environment (what torch.distributed.run gives the only rank of
+    `--nproc-per-node 1`): the barrier, the max-reduce and the all-gather run over a process group, as with 8."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = run(["--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"],
+            env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["timing_collectives"] == "gloo" and out["n_gpus"] == 1 and len(out["per_rank_seconds"]) == 1
+    # without a launcher there is no group
+    r = run(["--gpus", "1", "--dry-run", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["timing_collectives"] is None

@@ -222,6 +222,35 @@ def test_full_hd_corner_against_oracle(phases_model):
     assert d.max() <= 1
 
 
+def test_full_hd_whole_frame_against_oracle(phases_model, direct_model):
+    """The benchmark size in full: every pixel of the 3840x2160 image and the whole conv_up1 tensor of one
+    1080p frame, as the product path computes them in the plan the headline number runs (a pass of eight
+    frames; the frame sits in the last slot), against the oracle with the same four phase filters and
+    against the graph as the reference states it (direct 5x5 on the upsampled tensor)."""
+    W, H = 1920, 1080
+    rgba = synthetic_rgba(W, H, 1080)
+    with S.SuperResolutionContext(W, H, batch=8) as ctx:
+        assert ctx.frames_per_launch == 8
+        ctx.upload_rgba8(7, rgba)
+        ctx.upscale()
+        ctx.sync()
+        img = ctx.tensor_to_image(7)
+        a4 = ctx.read_tensor(4, frame=7)
+    for model, tol in ((phases_model, 1e-2), (direct_model, TENSOR_TOL)):
+        ref = model.run(rgba, keep_tensors=True)
+        eq, mx = check_image(img, ref)
+        want = model.tensor(4)
+        assert want.shape == a4.shape
+        err = max(float(np.abs(a4[c:c + 8].astype(np.float32) - want[c:c + 8]).max()) for c in range(0, 32, 8))
+        assert err <= tol, err
+        assert mx <= 1 and eq >= 0.99, (mx, eq)
+        del want, ref
+    # free the oracle's kept 1080p tensors (several GB of float32)
+    small = synthetic_rgba(8, 8, 1)
+    phases_model.run(small)
+    direct_model.run(small)
+
+
 def test_invalid_arguments():
     L = S.lib()
     import ctypes as C
