@@ -150,7 +150,7 @@ def pcie_inclusive(S, frames, device):
         for j in range(jobs + slots):
             s_ = j % slots
             if j >= slots:
-                pipe.wait(s_, view=True)
+                pipe.wait(s_)
                 done_at.append(time.perf_counter())
             if j < jobs:
                 pipe.submit(s_)

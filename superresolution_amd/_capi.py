@@ -286,15 +286,16 @@ class FramePipe:
     def submit(self, slot):
         _check(self._L.srx_pipe_submit(self._h, slot))
 
-    def wait(self, slot, view=False):
+    def wait(self, slot, copy=False):
         """Block until the slot is done; returns its output frames [frames_per_slot, 2H, 2W, channels].
-        By default a copy, which outlives the pipe; view=True returns the pinned buffer itself, valid
-        until the slot is submitted again or the pipe is closed."""
+        By default the pinned buffer itself (what srx_pipe_wait hands a C caller: no host copy), valid
+        until the slot is submitted again or the pipe is closed; copy=True returns a copy that outlives
+        both, at the price of one host memcpy of the slot (25 MB per 1080p RGB frame)."""
         ptr, pitch, stride = C.c_void_p(), C.c_size_t(), C.c_size_t()
         _check(self._L.srx_pipe_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(stride)))
         out = self._view(ptr.value, self.frames_per_slot * stride.value).reshape(
             self.frames_per_slot, 2 * self._ctx.height, 2 * self._ctx.width, self.out_channels)
-        return out if view else out.copy()
+        return out.copy() if copy else out
 
 
 def _sizes(v):

@@ -4,8 +4,14 @@
 //
 //   srx_main [-i|-image <png>] [-uma] [-warp]        the reference's switches
 //            [-frames N] [-update] [-o out.png] [-device D] [-devices D0,D1,...] [-noshot]
+//            [-stream N [-slot F]]
 // By default five frames are rendered with F11 "pressed" before the first one, so
 // a SuperResolutionX_<timestamp>.png appears like the reference's screen shot.
+//
+// -stream N runs the throughput configuration: N video frames (the input file, repeated) go from host
+// memory through the GPU and back in slots of F frames (default 8), three slots in flight (the
+// reference's FrameCount), and the program prints frames per second, host to host.  With -devices
+// every listed device runs its share of the N frames that way.
 //
 // -devices lists the GPUs of a multi-GPU run (the reference picks ONE adapter,
 // SuperResolutionX.cpp:76-117; frames are independent, so here every listed device gets
@@ -29,6 +35,7 @@ namespace {
 struct Options
 {
     int frames = 5;
+    int stream = 0, slot = 8;             // -stream N: frames of the throughput run; -slot F: frames per slot
     bool update = false, shot = true;
     std::string outPath;
     std::vector<std::wstring> wide;       // what the class's own ParseCommandLineArgs sees
@@ -44,6 +51,29 @@ void runInstance(const Options& opt, int device, int frames, bool update, bool s
     SuperResolutionX superResolutionX(1280, 720, L"Super resolution");
     superResolutionX.ParseCommandLineArgs(wargv.data(), int(wargv.size()));
     superResolutionX.SetDeviceIndex(device);
+    if (opt.stream > 0)
+    {
+        // frames = this instance's share of the stream; every OnRender submits one slot of them
+        superResolutionX.SetStreamMode(uint32_t(opt.slot));
+        superResolutionX.OnInit();
+        if (!quiet) std::printf("output %ux%u\n", superResolutionX.GetWidth(), superResolutionX.GetHeight());
+        const int slots = (frames + opt.slot - 1) / opt.slot;
+        const auto s0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < slots; ++f)
+        {
+            superResolutionX.OnUpdate();
+            superResolutionX.OnRender();
+        }
+        superResolutionX.Drain();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+        std::printf("stream on device %d: %llu frames in %.4f s = %.1f frames/s host to host (%d frames per slot, 3 slots in flight); "
+                    "%.1f frames/s between the first and the last slot's arrival\n",
+                    device, static_cast<unsigned long long>(superResolutionX.GetFramesCompleted()), dt,
+                    double(superResolutionX.GetFramesCompleted()) / dt, opt.slot, superResolutionX.GetSteadyFramesPerSecond());
+        if (!outPath.empty()) superResolutionX.SaveFrame(outPath.c_str());
+        superResolutionX.OnDestroy();
+        return;
+    }
     superResolutionX.OnInit();
     if (!quiet) std::printf("output %ux%u\n", superResolutionX.GetWidth(), superResolutionX.GetHeight());
     if (update) superResolutionX.OnKeyUp('U');
@@ -57,11 +87,14 @@ void runInstance(const Options& opt, int device, int frames, bool update, bool s
     superResolutionX.OnDestroy();
 }
 
+// "dir/name.png" -> "dir/name.<k>.png"; the extension is looked for in the file name only.
 std::string indexedPath(const std::string& path, size_t k)
 {
+    const size_t slash = path.find_last_of('/');
+    const size_t nameStart = slash == std::string::npos ? 0 : slash + 1;
     const size_t dot = path.find_last_of('.');
     const std::string tag = "." + std::to_string(k);
-    return dot == std::string::npos ? path + tag : path.substr(0, dot) + tag + path.substr(dot);
+    return (dot == std::string::npos || dot <= nameStart) ? path + tag : path.substr(0, dot) + tag + path.substr(dot);
 }
 
 }  // namespace
@@ -76,6 +109,8 @@ int main(int argc, char* argv[])
         const char* a = argv[i];
         const bool sw = i > 0 && (a[0] == '-' || a[0] == '/');
         if (sw && !strcasecmp(a + 1, "frames") && i + 1 < argc) { opt.frames = std::atoi(argv[++i]); continue; }
+        if (sw && !strcasecmp(a + 1, "stream") && i + 1 < argc) { opt.stream = std::atoi(argv[++i]); continue; }
+        if (sw && !strcasecmp(a + 1, "slot") && i + 1 < argc) { opt.slot = std::atoi(argv[++i]); continue; }
         if (sw && !strcasecmp(a + 1, "device") && i + 1 < argc) { device = std::atoi(argv[++i]); continue; }
         if (sw && !strcasecmp(a + 1, "devices") && i + 1 < argc)
         {
@@ -95,11 +130,17 @@ int main(int argc, char* argv[])
         opt.wide.emplace_back(a, a + std::strlen(a));
     }
 
+    if (opt.stream < 0 || opt.slot < 1 || opt.slot > 64)
+    {
+        std::fprintf(stderr, "error: -stream expects a frame count, -slot 1..64 frames per slot\n");
+        return 1;
+    }
+    const int total = opt.stream > 0 ? opt.stream : opt.frames;
     if (devices.empty())
     {
         try
         {
-            runInstance(opt, device, opt.frames, opt.update, opt.shot, opt.outPath, false);
+            runInstance(opt, device, total, opt.update, opt.shot, opt.outPath, false);
         }
         catch (const std::exception& e)
         {
@@ -118,7 +159,8 @@ int main(int argc, char* argv[])
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < G; ++k)
     {
-        share[k] = (opt.frames > int(k)) ? (opt.frames - int(k) + int(G) - 1) / int(G) : 0;
+        share[k] = (total > int(k)) ? (total - int(k) + int(G) - 1) / int(G) : 0;
+        if (share[k] == 0) continue;          // more instances than frames: this one has nothing to render or save
         threads.emplace_back([&, k] {
             try
             {
@@ -142,6 +184,11 @@ int main(int argc, char* argv[])
         {
             std::fprintf(stderr, "error: instance %zu (device %d): %s\n", k, devices[k], errors[k].c_str());
             rc = 1;
+            continue;
+        }
+        if (share[k] == 0)
+        {
+            std::printf("instance %zu on device %d: no frames\n", k, devices[k]);
             continue;
         }
         done += share[k];

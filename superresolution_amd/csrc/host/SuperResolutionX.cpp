@@ -38,6 +38,12 @@ SuperResolutionX::SuperResolutionX(uint32_t width, uint32_t height, std::wstring
     m_deviceIndex(0),
     m_stream(nullptr),
     m_frameIndex(0),
+    m_fenceEvents{},
+    m_framePending{},
+    m_framesPerSlot(0),
+    m_framesCompleted(0),
+    m_slotsCompleted(0),
+    m_lastOutput(nullptr),
     m_deviceType(DEVICE_DISCRETE),
     m_updateImage(false),
     m_showFPS(true),
@@ -81,8 +87,15 @@ void SuperResolutionX::LoadPipeline()
     m_width = m_superResolution->GetOutWidth();
     m_height = m_superResolution->GetOutHeight();
 
-    // Create frame resources: one render target per frame in flight.
-    for (uint8_t n = 0; n < FrameCount; ++n) m_renderTargets[n].Create(m_width, m_height);
+    // Create frame resources: one render target and one fence event per frame in flight.  In stream mode the
+    // slots' page-locked output buffers are the render targets.
+    for (uint8_t n = 0; n < FrameCount; ++n)
+    {
+        if (!m_framesPerSlot) m_renderTargets[n].Create(m_width, m_height);
+        hipEvent_t ev = nullptr;
+        ThrowIfFailed(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        m_fenceEvents[n] = ev;
+    }
 }
 
 // Load the sample assets: wait until the uploads of Init have reached the GPU.
@@ -95,6 +108,8 @@ void SuperResolutionX::LoadAssets()
 bool SuperResolutionX::InitTensors()
 {
     m_superResolution = make_unique<SuperResolution>();
+    if (m_framesPerSlot)
+        return m_superResolution->InitStream(m_deviceIndex, m_vendorId, m_fileName.c_str(), m_isFP16Supported, FrameCount, m_framesPerSlot);
     // fp16 tensors are always supported on gfx950 (the reference queries DirectML for this)
     return m_superResolution->Init(m_stream, m_deviceIndex, m_vendorId, m_fileName.c_str(), m_isFP16Supported);
 }
@@ -121,6 +136,11 @@ void SuperResolutionX::OnDestroy()
     // cleaned up by the destructor.
     WaitForGpu();
     m_superResolution.reset();
+    for (uint8_t n = 0; n < FrameCount; ++n)
+    {
+        if (m_fenceEvents[n]) (void)hipEventDestroy(static_cast<hipEvent_t>(m_fenceEvents[n]));
+        m_fenceEvents[n] = nullptr;
+    }
     if (m_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(m_stream));
     m_stream = nullptr;
 }
@@ -188,6 +208,17 @@ void SuperResolutionX::ParseCommandLineArgs(wchar_t* argv[], int argc)
 
 void SuperResolutionX::PopulateCommandList()
 {
+    if (m_framesPerSlot)
+    {
+        // Stream mode: the slot of this frame index is free (MoveToNextFrame waited for it).  A video source
+        // would write the slot's next frames into GetStreamInput(m_frameIndex) here; then the whole slot is
+        // recorded and submitted: upload, ImageToTensors + Process, copy into the slot's render targets.
+        m_superResolution->SubmitFrames(m_frameIndex);
+        m_framePending[m_frameIndex] = true;
+        m_isFirstFrame = false;
+        return;
+    }
+
     if (m_isFirstFrame || m_updateImage)
     {
         m_superResolution->ImageToTensors(m_stream);
@@ -197,6 +228,10 @@ void SuperResolutionX::PopulateCommandList()
 
     RenderTarget* pRenderTarget = &m_renderTargets[m_frameIndex];
     m_superResolution->Render(m_stream, pRenderTarget);
+    // the frame's fence: signalled when its render target holds the picture
+    ThrowIfFailed(hipEventRecord(static_cast<hipEvent_t>(m_fenceEvents[m_frameIndex]), static_cast<hipStream_t>(m_stream)) == hipSuccess,
+                  "hipEventRecord failed");
+    m_framePending[m_frameIndex] = true;
 
     // Screen-shot helper
     if (m_screenShot == 1)
@@ -210,15 +245,46 @@ void SuperResolutionX::PopulateCommandList()
 // Wait for pending GPU work to complete.
 void SuperResolutionX::WaitForGpu()
 {
-    ThrowIfFailed(hipStreamSynchronize(static_cast<hipStream_t>(m_stream)) == hipSuccess, "hipStreamSynchronize failed");
+    // every frame in flight, oldest first
+    for (uint32_t n = 1; n <= FrameCount; ++n) WaitForFrame((m_frameIndex + n) % FrameCount);
+    if (m_stream)
+        ThrowIfFailed(hipStreamSynchronize(static_cast<hipStream_t>(m_stream)) == hipSuccess, "hipStreamSynchronize failed");
+}
+
+// The fence wait of one frame in flight: returns once its render target holds the picture.
+void SuperResolutionX::WaitForFrame(uint32_t index)
+{
+    if (!m_framePending[index]) return;
+    if (m_framesPerSlot)
+    {
+        size_t pitch = 0, stride = 0;
+        m_lastOutput = m_superResolution->WaitFrames(index, &pitch, &stride);
+        m_lastSlotTime = chrono::steady_clock::now();
+        if (m_slotsCompleted++ == 0) m_firstSlotTime = m_lastSlotTime;
+        m_framesCompleted += m_framesPerSlot;
+    }
+    else
+    {
+        ThrowIfFailed(hipEventSynchronize(static_cast<hipEvent_t>(m_fenceEvents[index])) == hipSuccess, "hipEventSynchronize failed");
+        ++m_framesCompleted;
+    }
+    m_framePending[index] = false;
+}
+
+double SuperResolutionX::GetSteadyFramesPerSecond() const
+{
+    if (m_slotsCompleted < 2) return 0.0;
+    const double dt = chrono::duration<double>(m_lastSlotTime - m_firstSlotTime).count();
+    return dt > 0.0 ? double(m_slotsCompleted - 1) * m_framesPerSlot / dt : 0.0;
 }
 
 // Prepare to render the next frame.
 void SuperResolutionX::MoveToNextFrame()
 {
-    // One in-order stream: a render target is reusable once the copy into it has completed.
-    WaitForGpu();
+    // Update the frame index; if the next frame is not ready to be rendered yet (its render target, or its
+    // slot, still has work in flight), wait until it is.  The other frames stay in flight.
     m_frameIndex = (m_frameIndex + 1) % FrameCount;
+    WaitForFrame(m_frameIndex);
 
     // Screen-shot helper: the reference saves FrameCount frames after the request
     if (m_screenShot)
@@ -241,7 +307,7 @@ void SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImag
                                  uint32_t rowPitch, uint8_t comp)
 {
     assert(comp == 3 || comp == 4);
-    const uint8_t* pData = pImageBuffer->pixels.data();
+    const uint8_t* pData = pImageBuffer->pixels;
 
     // strip the row pitch and (comp == 3) the alpha channel
     vector<uint8_t> imageData(size_t(comp) * w * h);
@@ -257,6 +323,19 @@ void SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImag
 
 bool SuperResolutionX::SaveFrame(const char* fileName)
 {
+    WaitForGpu();
+    if (m_framesPerSlot)
+    {
+        // the first frame of the slot that arrived last: RGB8, tightly packed
+        if (!m_lastOutput) return false;
+        if (!srx::WritePng(fileName, int(m_width), int(m_height), 3, m_lastOutput, 0))
+        {
+            cerr << "SaveImage: " << srx::LastImageError() << endl;
+            return false;
+        }
+        cout << "Saved " << fileName << endl;
+        return true;
+    }
     const uint32_t last = (m_frameIndex + FrameCount - 1) % FrameCount;
     SaveImage(fileName, &m_renderTargets[last], m_width, m_height, m_renderTargets[last].rowPitch);
     return true;

@@ -5,9 +5,9 @@
 // reference (SuperResolutionX.h:26-39): constructor (width, height, name) and the
 // DXFramework overrides OnInit / OnUpdate / OnRender / OnDestroy / OnKeyUp /
 // ParseCommandLineArgs.  The D3D12 device, swap chain, command allocators and
-// fence of the reference become: a HIP device index, FrameCount host render
-// targets, and an in-order HIP stream that is drained where the reference waits
-// on its fence.
+// fence of the reference become: a HIP device index, FrameCount page-locked host
+// render targets, an in-order HIP stream, and one event per frame in flight that
+// is waited for where the reference waits on that frame's fence value.
 #pragma once
 
 #include <chrono>
@@ -37,6 +37,18 @@ public:
     bool SaveFrame(const char* fileName);
     double GetLastFps() const { return m_lastFps; }
 
+    // Stream mode (before OnInit): every OnRender submits one slot of `framesPerSlot` video frames (upload,
+    // ImageToTensors + Process, copy back) and returns; FrameCount slots are in flight and MoveToNextFrame waits
+    // only for the slot it is about to reuse, as the reference does with its fence values
+    // (SuperResolutionX.cpp:388-405).  The input file stands in for the video source.
+    void SetStreamMode(uint32_t framesPerSlot) { m_framesPerSlot = framesPerSlot; }
+    uint32_t GetFramesPerSlot() const { return m_framesPerSlot; }
+    // Frames whose output has arrived in host memory, and when the first and the latest slot arrived.
+    uint64_t GetFramesCompleted() const { return m_framesCompleted; }
+    double GetSteadyFramesPerSecond() const;
+    // Wait for every frame in flight (OnDestroy does so too).
+    void Drain() { WaitForGpu(); }
+
 private:
     enum DeviceType : uint8_t
     {
@@ -58,6 +70,15 @@ private:
 
     // Synchronization objects.
     uint32_t m_frameIndex;
+    void* m_fenceEvents[FrameCount];      // hipEvent_t, recorded after a frame's last command
+    bool m_framePending[FrameCount];      // the frame (or slot) of this index has work in flight
+
+    // Stream mode
+    uint32_t m_framesPerSlot;             // 0 = one image per frame, as the reference
+    uint64_t m_framesCompleted;
+    uint32_t m_slotsCompleted;
+    std::chrono::steady_clock::time_point m_firstSlotTime, m_lastSlotTime;
+    const uint8_t* m_lastOutput;          // first frame of the slot that arrived last (RGB8, tightly packed)
 
     // Application state
     DeviceType m_deviceType;
@@ -84,6 +105,7 @@ private:
 
     void PopulateCommandList();
     void WaitForGpu();
+    void WaitForFrame(uint32_t index);
     void MoveToNextFrame();
     void SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
                    uint32_t rowPitch, uint8_t comp = 3);

@@ -103,16 +103,30 @@ srx_status staticScratchFor(int device, void** out)
     return SRX_OK;
 }
 
-// Layout of conv_up1's output for one w x h input frame, as both fused kernels address it.
-struct Up1Layout { int pitch, rows; size_t bytes; };
-Up1Layout up1Layout(uint32_t w, uint32_t h)
+// Layout of tensor `id` for one w x h input frame, as the kernels address it: the one place that knows the
+// border, the padding to whole tiles and the slack (the ctx workspace and srx_upscale_static both use it).
+struct TensorPlacement { int pitch, rows; int64_t frameHalfs; size_t bytes, baseOffsetHalfs; };
+TensorPlacement tensorPlacement(int id, uint32_t w, uint32_t h)
 {
-    const TensorInfo& ti = kTensorInfo[SRX_T_CONV_UP1];
-    Up1Layout l;
+    const TensorInfo& ti = kTensorInfo[id];
+    TensorPlacement l;
     l.pitch = roundUp(int(w) * ti.scale, srx::kTileW) + 2 * ti.border + ti.slackRight;
     l.rows = roundUp(int(h) * ti.scale, srx::kTileH) + 2 * ti.border;
-    l.bytes = size_t(l.pitch) * l.rows * ti.storedChannels * 2;
+    l.frameHalfs = int64_t(l.pitch) * l.rows * ti.storedChannels;
+    l.bytes = size_t(l.frameHalfs) * 2;
+    l.baseOffsetHalfs = (size_t(ti.border) * l.pitch + ti.border) * ti.storedChannels;   // image pixel (0, 0)
     return l;
+}
+
+// The Tensor the kernels take for `id` in memory that starts at `mem`.
+srx::Tensor tensorAt(int id, const TensorPlacement& l, void* mem)
+{
+    srx::Tensor t;
+    t.channels = kTensorInfo[id].storedChannels;
+    t.pitch = l.pitch;
+    t.frame = l.frameHalfs;
+    t.base = static_cast<uint16_t*>(mem) + l.baseOffsetHalfs;
+    return t;
 }
 
 }  // namespace
@@ -123,6 +137,9 @@ struct srx_ctx
     int numCUs = 256;
     uint32_t width = 0, height = 0, batch = 0, flags = 0;
     uint32_t chunk = 0;                      // frames of activation workspace (<= batch)
+    // frames whose conv_up1 tensor the workspace holds: slot i = frame residentFirst + i (fused path; set by the
+    // last launch of the first fused kernel through this ctx's workspace)
+    uint32_t residentFirst = 0, residentCount = 0;
 
     srx::FoldedWeights folded;
     uint16_t* wpk[srx::kNumConvLayers] = {};
@@ -244,16 +261,12 @@ srx_status allocTensors(srx_ctx* c)
     size_t perFrame = 0;
     for (int id = 0; id < SRX_T_COUNT; ++id)
     {
-        const TensorInfo& ti = kTensorInfo[id];
         if (id != SRX_T_CONV_UP1 && !c->keep()) continue;   // the fused kernels keep the rest in LDS
-        const int w = int(c->width) * ti.scale, h = int(c->height) * ti.scale;
-        const int pitch = roundUp(w, srx::kTileW) + 2 * ti.border + ti.slackRight;
-        const int rows = roundUp(h, srx::kTileH) + 2 * ti.border;
-        c->tensor[id].channels = ti.storedChannels;
-        c->tensor[id].pitch = pitch;
-        c->tensor[id].frame = int64_t(pitch) * rows * ti.storedChannels;
-        c->tensorRows[id] = rows;
-        c->tensorFrameBytes[id] = size_t(c->tensor[id].frame) * 2;
+        const TensorPlacement lay = tensorPlacement(id, c->width, c->height);
+        c->tensor[id] = tensorAt(id, lay, nullptr);          // base is set once the memory exists
+        c->tensor[id].base = nullptr;
+        c->tensorRows[id] = lay.rows;
+        c->tensorFrameBytes[id] = lay.bytes;
         if (id != SRX_T_INPUT) perFrame += c->tensorFrameBytes[id];
     }
     // Frames resident per pass.  Small images are batched into one launch per stage so that the
@@ -303,9 +316,7 @@ srx_status allocTensors(srx_ctx* c)
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, c->tensorFrameBytes[id] * frames)) return s;
         c->tensorAlloc[id] = d;
-        const TensorInfo& ti = kTensorInfo[id];
-        c->tensor[id].base = static_cast<uint16_t*>(d) +
-                             (size_t(ti.border) * c->tensor[id].pitch + ti.border) * ti.storedChannels;
+        c->tensor[id] = tensorAt(id, tensorPlacement(id, c->width, c->height), d);
     }
     return SRX_OK;
 }
@@ -441,6 +452,8 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
         ll.height = H;
         ll.batch = int(count);
         SRX_HIP(LaunchLrFused(ll, c->numCUs, s));
+        c->residentFirst = first;
+        c->residentCount = count;
         return SRX_OK;
     }
     const int l = int(stage) - int(ST_CONV1);
@@ -712,7 +725,7 @@ srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* 
     if (inPitch < size_t(w) * 4 || outPitch < size_t(w) * 8 || (inPitch & 3) || (outPitch & 3) ||
         (reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3))
         return fail(SRX_ERR_INVALID, "srx_upscale_static: pitches must cover a row (4 bytes per pixel) and, like the pointers, be multiples of 4");
-    const Up1Layout lay = up1Layout(w, h);
+    const TensorPlacement lay = tensorPlacement(SRX_T_CONV_UP1, w, h);
     if (lay.bytes > kStaticScratchBytes)
         return fail(SRX_ERR_INVALID, "srx_upscale_static: image too large for the static workspace: 64 bytes per output pixel plus borders "
                                      "must fit " + std::to_string(kStaticScratchBytes >> 20) + " MiB (e.g. 640x360 fits, 1280x720 does not); "
@@ -728,12 +741,7 @@ srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* 
     // the memset was seen to run beside the kernel that follows it).
     SRX_HIP(srx::LaunchZero(c->staticScratch, lay.bytes, st));
 
-    const TensorInfo& ti = kTensorInfo[SRX_T_CONV_UP1];
-    srx::Tensor a4;
-    a4.channels = ti.storedChannels;
-    a4.pitch = lay.pitch;
-    a4.frame = int64_t(lay.pitch) * lay.rows * ti.storedChannels;
-    a4.base = static_cast<uint16_t*>(c->staticScratch) + (size_t(ti.border) * lay.pitch + ti.border) * ti.storedChannels;
+    const srx::Tensor a4 = tensorAt(SRX_T_CONV_UP1, lay, c->staticScratch);
     srx::Image src, dst;
     src.base = static_cast<uint8_t*>(const_cast<void*>(in));
     src.pitch = int64_t(inPitch);
@@ -820,9 +828,17 @@ srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, si
     // after srx_upscale / srx_process it still holds every frame when one pass covers the whole batch.
     if (!c->keep() && !c->generic() && id != SRX_T_CONV_UP1)
         return fail(SRX_ERR_STATE, "srx_read_tensor needs SRX_FLAG_KEEP_TENSORS at srx_create (without it only SRX_T_CONV_UP1 reaches HBM)");
-    if (!c->keep() && !c->generic() && c->chunk < c->batch)
-        return fail(SRX_ERR_STATE, "srx_read_tensor(SRX_T_CONV_UP1): the batch runs in several passes that share one workspace; "
-                                   "use a batch of at most srx_frames_per_launch() frames");
+    // On the fused path the workspace holds the frames of the last pass only, slot i = frame residentFirst + i.
+    uint32_t slot = frame;
+    if (!c->keep() && !c->generic())
+    {
+        if (frame < c->residentFirst || frame - c->residentFirst >= c->residentCount)
+            return fail(SRX_ERR_STATE, "srx_read_tensor(SRX_T_CONV_UP1): frame " + std::to_string(frame) + " is not in the workspace, which holds "
+                                       "the " + std::to_string(c->residentCount) + " frame(s) from " + std::to_string(c->residentFirst) +
+                                       " on of the last pass (nothing before the first upscale; a batch above srx_frames_per_launch() "
+                                       "runs in several passes that share one workspace; srx_upscale_static does not use it)");
+        slot = frame - c->residentFirst;
+    }
     const TensorInfo& ti = kTensorInfo[id];
     const size_t H = size_t(c->height) * ti.scale, W = size_t(c->width) * ti.scale;
     if (c->generic())
@@ -848,7 +864,7 @@ srx_status srx_read_tensor(srx_ctx* c, uint32_t frame, int32_t id, void* out, si
     SRX_HIP(hipSetDevice(c->device));
     SRX_HIP(hipDeviceSynchronize());
     std::vector<uint16_t> raw(c->tensorFrameBytes[id] / 2);
-    SRX_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t*>(c->tensorAlloc[id]) + size_t(frame) * c->tensorFrameBytes[id],
+    SRX_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t*>(c->tensorAlloc[id]) + size_t(slot) * c->tensorFrameBytes[id],
                       c->tensorFrameBytes[id], hipMemcpyDeviceToHost));
     const srx::Tensor& t = c->tensor[id];
     uint16_t* dst = static_cast<uint16_t*>(out);

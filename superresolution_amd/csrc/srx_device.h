@@ -6,6 +6,14 @@
 
 #include "srx_kernels.h"
 
+// SRX_DIAG=1 (make DIAG=1, a separate libsrx_diag.so) compiles the diagnostic variants of the two fused
+// kernels, the in-kernel clock probe and the environment switches that select them (SRX_EXP, SRX_EXP_LR,
+// SRX_LR_PRIO, SRX_CLOCK; read once per process).  The shipping library holds one instantiation of each fused
+// kernel and reads no environment variable on a launch.
+#ifndef SRX_DIAG
+#define SRX_DIAG 0
+#endif
+
 namespace srx {
 
 typedef _Float16 f16;
@@ -77,7 +85,8 @@ __device__ __forceinline__ void barrierLds()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Diagnostic: when the environment variable SRX_CLOCK is set, a kernel's workgroups record how many
+#if SRX_DIAG
+// Diagnostic (SRX_DIAG builds only): when the environment variable SRX_CLOCK is set, a kernel's workgroups record how many
 // shader cycles and how many 100-MHz reference ticks they ran for, and the launcher prints the
 // resulting in-kernel clock after a number of launches.  The buffer is read by no kernel.  There is
 // one probe per (device, kernel): the table behind clockProbeFor is guarded by a mutex, so launches
@@ -89,11 +98,16 @@ struct ClockProbe
 };
 enum ProbedKernel { PROBE_LR_FUSED = 0, PROBE_HR_FUSED = 1, PROBE_COUNT };
 // The probe of `kernel` on the current device, with its buffer allocated; nullptr when SRX_CLOCK is unset,
-// when `blocks` exceeds the buffer, or when `mayAllocate` is false and the buffer does not exist yet.
-ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate);
+// when `blocks` exceeds the buffer, when `mayAllocate` is false (a launch that must neither allocate nor
+// synchronise: the report does both) or when stream `s` is being captured into a graph.
+ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate, hipStream_t s);
 void clockProbeReport(ClockProbe* probe, const char* name, int blocks, hipStream_t s, int extraWords = 0);
+// Integer value of an environment variable, `fallback` when unset.
+int diagEnvInt(const char* name, int fallback);
+#endif  // SRX_DIAG
 
-// Raise a kernel's dynamic shared memory limit, once per (device, kernel).  Thread-safe.
+// Raise a kernel's dynamic shared memory limit, once per (device, kernel).  Thread-safe.  Called at set-up
+// (PrepareFusedKernels, from srx_create), not on a launch.
 hipError_t ensureDynamicLds(const void* kernel, int bytes);
 
 inline TensorD toDevice(const Tensor& t) { return TensorD{reinterpret_cast<f16*>(t.base), t.pitch, long(t.frame)}; }

@@ -56,7 +56,6 @@
 // and PSTensorToImage.hlsl:14-35 + the R8G8B8A8_UNORM render target.
 #include "srx_device.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace srx {
@@ -115,9 +114,10 @@ __device__ __forceinline__ void phaseBarrier()
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// EXP (diagnostic build variants, env SRX_EXP): 1 = no scheduling pins inside the phases; 2 = no raised priority
+// EXP (variants of SRX_DIAG builds, env SRX_EXP): 1 = no scheduling pins inside the phases; 2 = no raised priority
 // in the matrix phase; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave spends in the
-// load phase, waiting at its barrier, in the matrix phase and waiting at that barrier.
+// load phase, waiting at its barrier, in the matrix phase and waiting at that barrier.  The shipping library
+// instantiates EXP = 0 only.
 template <int EXP>
 __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 {
@@ -133,7 +133,12 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int L = w4 >> 1, ti = w4 & 1;
     char* const smem = smemAll + G * kHrGroupSmem;
 
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long clk0 = 0, ref0 = 0;
+    if constexpr (SRX_DIAG != 0)
+    {
+        clk0 = __builtin_amdgcn_s_memtime();
+        ref0 = __builtin_amdgcn_s_memrealtime();
+    }
     f16x8 wmain[18];
     {
         const f16x8* src = L ? p.wpk5 : p.wpk4;
@@ -452,11 +457,12 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             if (p.clock && lane == 0 && blockIdx.x < 16)
                 for (int k = 0; k < 8; ++k) p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = spent[k];
     }
-    if (p.clock && tid == 0)
-    {
-        p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
-        p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
-    }
+    if constexpr (SRX_DIAG != 0)
+        if (p.clock && tid == 0)
+        {
+            p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+            p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
+        }
 }
 
 }  // namespace
@@ -491,9 +497,27 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     return pl;
 }
 
+#if SRX_DIAG
+namespace {
+int hrDiagExp()
+{
+    static const int exp = diagEnvInt("SRX_EXP", 0);
+    return exp;
+}
+}  // namespace
+#endif
+
 hipError_t PrepareHrFused()
 {
-    return ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0>), kHrSmem);
+    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0>), kHrSmem);
+#if SRX_DIAG
+    (void)hrDiagExp();
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<1>), kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<2>), kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<3>), kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<4>), kHrSmem);
+#endif
+    return e;
 }
 
 hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
@@ -522,26 +546,26 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     // one input and one output frame must be addressable with a 32-bit byte offset
     if (p.imageFrame >= (1L << 31) || p.inputFrame >= (1L << 31)) return hipErrorInvalidValue;
 
-    const char* env = getenv("SRX_EXP");
-    const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor((p.numItems + 1) / 2, numCUs, 1)), block(kHrThreads);
-#define SRX_HR_CASE(E)                                                                                       \
-    case E: {                                                                                                \
-        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<E>), kHrSmem);     \
-        if (e != hipSuccess) return e;                                                                       \
-        hipLaunchKernelGGL(HrFusedKernel<E>, grid, block, kHrSmem, s, p);                                    \
-        break;                                                                                               \
-    }
-    ClockProbe* const probe = clockProbeFor(PROBE_HR_FUSED, int(grid.x), l.mayAllocate);
+    // The kernel was loaded and its shared-memory limit raised by PrepareFusedKernels (srx_create): a launch is
+    // the launch and nothing else.
+#if SRX_DIAG
+    const int exp = hrDiagExp();
+    ClockProbe* const probe = clockProbeFor(PROBE_HR_FUSED, int(grid.x), l.mayAllocate, s);
     p.clock = probe ? probe->dev : nullptr;
     switch (exp)
     {
-        SRX_HR_CASE(1) SRX_HR_CASE(2) SRX_HR_CASE(3) SRX_HR_CASE(4)
-    default:
-        SRX_HR_CASE(0)
+    case 1: hipLaunchKernelGGL(HrFusedKernel<1>, grid, block, kHrSmem, s, p); break;
+    case 2: hipLaunchKernelGGL(HrFusedKernel<2>, grid, block, kHrSmem, s, p); break;
+    case 3: hipLaunchKernelGGL(HrFusedKernel<3>, grid, block, kHrSmem, s, p); break;
+    case 4: hipLaunchKernelGGL(HrFusedKernel<4>, grid, block, kHrSmem, s, p); break;
+    default: hipLaunchKernelGGL(HrFusedKernel<0>, grid, block, kHrSmem, s, p); break;
     }
-#undef SRX_HR_CASE
     clockProbeReport(probe, "HrFusedKernel", int(grid.x), s, exp == 4 ? 1024 : 0);
+#else
+    p.clock = nullptr;
+    hipLaunchKernelGGL(HrFusedKernel<0>, grid, block, kHrSmem, s, p);
+#endif
     return hipGetLastError();
 }
 

@@ -329,10 +329,19 @@ std::mutex g_launchStateMutex;
 constexpr int kMaxDevices = 64, kProbeBlocks = 4096;
 }
 
-ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate)
+#if SRX_DIAG
+int diagEnvInt(const char* name, int fallback)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : fallback;
+}
+
+ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate, hipStream_t s)
 {
     static const bool on = getenv("SRX_CLOCK") != nullptr;
-    if (!on || blocks > kProbeBlocks) return nullptr;
+    if (!on || blocks > kProbeBlocks || !mayAllocate) return nullptr;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return nullptr;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
     static ClockProbe probes[kMaxDevices][PROBE_COUNT];
@@ -340,7 +349,6 @@ ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate)
     ClockProbe& probe = probes[device][kernel];
     if (!probe.dev)
     {
-        if (!mayAllocate) return nullptr;
         if (hipMalloc(&probe.dev, 2 * kProbeBlocks * sizeof(unsigned long long)) != hipSuccess)
         {
             probe.dev = nullptr;
@@ -349,6 +357,8 @@ ClockProbe* clockProbeFor(ProbedKernel kernel, int blocks, bool mayAllocate)
     }
     return &probe;
 }
+
+#endif  // SRX_DIAG
 
 hipError_t ensureDynamicLds(const void* kernel, int bytes)
 {
@@ -363,6 +373,7 @@ hipError_t ensureDynamicLds(const void* kernel, int bytes)
     return r;
 }
 
+#if SRX_DIAG
 void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStream_t s, int extraWords)
 {
     if (!probePtr) return;
@@ -403,6 +414,8 @@ void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStr
     for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xcdUs[x]);
     fprintf(stderr, "\n");
 }
+
+#endif  // SRX_DIAG
 
 }  // namespace dev
 

@@ -411,7 +411,8 @@ hipError_t DispatchOperator(const ML::Operator& op, const void* input, const voi
         a.tilesY = (a.H + kTH - 1) / kTH;
         if (a.N > 65535 || (a.O + kOT - 1) / kOT > 65535) return hipErrorInvalidValue;
         const dim3 grid(a.tilesX * a.tilesY, (a.O + kOT - 1) / kOT, a.N), block(256);
-        if (op.dataType == ML::TensorDataType::FLOAT16 && !getenv("SRX_GENERIC_VALU"))
+        static const bool forceValu = getenv("SRX_GENERIC_VALU") != nullptr;      // read once per process
+        if (op.dataType == ML::TensorDataType::FLOAT16 && !forceValu)
         {
             // fp16 tensors run on the matrix cores (SRX_GENERIC_VALU keeps the direct kernel, for comparison)
             const int lds = convMfmaLdsBytes(a.kh, a.kw);

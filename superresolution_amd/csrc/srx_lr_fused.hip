@@ -36,7 +36,6 @@
 // (Content/SuperResolution.cpp:191-238 via ML::Util::CreateConvolutionLayer).
 #include "srx_device.h"
 
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -186,15 +185,20 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
     pre = nxt;
 }
 
-// EXP (diagnostic build variants, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
+// EXP (variants of SRX_DIAG builds, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
 // epilogue pieces itself; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave
-// waits at the step barrier.
+// waits at the step barrier.  The shipping library instantiates EXP = 0 only.
 template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool PIN = (EXP & 1) == 0;
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long clk0 = 0, ref0 = 0;
+    if constexpr (SRX_DIAG != 0)
+    {
+        clk0 = __builtin_amdgcn_s_memtime();
+        ref0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -579,11 +583,12 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     if constexpr ((EXP & 4) != 0)
         if (p.clock && lane == 0 && blockIdx.x < 16)
             for (int k = 0; k < 8; ++k) p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = k == 6 ? waited : 0;
-    if (p.clock && tid == 0)
-    {
-        p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
-        p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
-    }
+    if constexpr (SRX_DIAG != 0)
+        if (p.clock && tid == 0)
+        {
+            p.clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+            p.clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ref0;
+        }
 }
 
 }  // namespace
@@ -619,9 +624,27 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
 hipError_t PrepareHrFused();
 hipError_t PrepareZero();
 
+namespace {
+// Static priority of the roles (bit r: waves of role r run at priority 1): conv3, conv2 and conv1 above conv_up1.
+constexpr int kLrPrioMask = 14;
+#if SRX_DIAG
+struct LrDiag { int exp, prio; };
+const LrDiag& lrDiag()
+{
+    static const LrDiag d{diagEnvInt("SRX_EXP_LR", 0), diagEnvInt("SRX_LR_PRIO", kLrPrioMask)};
+    return d;
+}
+#endif
+}  // namespace
+
 hipError_t PrepareFusedKernels()
 {
     hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0>), kLrSmem);
+#if SRX_DIAG
+    (void)lrDiag();
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<1>), kLrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<4>), kLrSmem);
+#endif
     if (e == hipSuccess) e = PrepareHrFused();
     return e != hipSuccess ? e : PrepareZero();
 }
@@ -649,28 +672,26 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     // a row of a4 must be addressable with a 32-bit byte offset
     if (long(l.a4.pitch) * 64 >= (1L << 31)) return hipErrorInvalidValue;
 
-    const char* envPrio = getenv("SRX_LR_PRIO");
-    p.prioMask = envPrio ? atoi(envPrio) : 14;
-    const char* env = getenv("SRX_EXP_LR");
-    const int exp = env ? atoi(env) : 0;
     const dim3 grid(gridFor(p.numItems, numCUs, 1)), block(kLrThreads);
-    ClockProbe* const probe = clockProbeFor(PROBE_LR_FUSED, int(grid.x), l.mayAllocate);
+    // The kernels were loaded and their shared-memory limit raised by PrepareFusedKernels (srx_create): a
+    // launch is the launch and nothing else.
+#if SRX_DIAG
+    const int exp = lrDiag().exp;
+    p.prioMask = lrDiag().prio;
+    ClockProbe* const probe = clockProbeFor(PROBE_LR_FUSED, int(grid.x), l.mayAllocate, s);
     p.clock = probe ? probe->dev : nullptr;
-#define SRX_LR_CASE(E)                                                                                       \
-    case E: {                                                                                                \
-        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<E>), kLrSmem);     \
-        if (e != hipSuccess) return e;                                                                       \
-        hipLaunchKernelGGL(LrFusedKernel<E>, grid, block, kLrSmem, s, p);                                    \
-        break;                                                                                               \
-    }
     switch (exp)
     {
-        SRX_LR_CASE(1) SRX_LR_CASE(4)
-    default:
-        SRX_LR_CASE(0)
+    case 1: hipLaunchKernelGGL(LrFusedKernel<1>, grid, block, kLrSmem, s, p); break;
+    case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
+    default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
     }
-#undef SRX_LR_CASE
     clockProbeReport(probe, "LrFusedKernel", int(grid.x), s, (exp & 4) ? 1024 : 0);
+#else
+    p.prioMask = kLrPrioMask;
+    p.clock = nullptr;
+    hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p);
+#endif
     return hipGetLastError();
 }
 

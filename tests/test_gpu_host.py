@@ -121,3 +121,61 @@ def test_devices_switch_shards_frames_over_instances(workdir):
         assert np.array_equal(np.asarray(Image.open(workdir / f"multi.{k}.png")), want)
     r = run(["-devices", "0,99", "-frames", "2"], workdir)
     assert r.returncode != 0 and "device index out of range" in r.stderr
+
+
+def test_more_instances_than_frames_and_output_names(workdir):
+    """-devices with fewer frames than instances: the surplus instance renders and saves nothing; the index goes
+    in front of the extension of the file NAME, wherever the directory has dots."""
+    os.makedirs(workdir / "out.d")
+    r = run(["-i", "Assets/Sashimi128.png", "-devices", "0,0", "-frames", "1", "-o", "./out.d/name"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "instance 1 on device 0: no frames" in r.stdout and "1 frames on 2 instances" in r.stdout
+    assert os.path.exists(workdir / "out.d" / "name.0") and not os.path.exists(workdir / "out.d" / "name.1")
+    assert not glob.glob(str(workdir / ".0*"))
+
+
+def _stream_rate(stdout):
+    import re
+    m = re.search(r"= ([0-9.]+) frames/s host to host .*; ([0-9.]+) frames/s between", stdout)
+    assert m, stdout
+    return float(m.group(1)), float(m.group(2))
+
+
+def test_stream_mode_small_image_equals_single_frame_path(workdir):
+    """-stream: slots of frames in flight through the frame pipe (three slots, here four frames each); the
+    picture is the one the single-frame path renders."""
+    r = run(["-i", "Assets/Sashimi.png", "-o", "one.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    r = run(["-i", "Assets/Sashimi.png", "-stream", "42", "-slot", "4", "-o", "s.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert "stream on device 0: 44 frames" in r.stdout            # whole slots: 11 x 4
+    assert np.array_equal(np.asarray(Image.open(workdir / "s.png")), np.asarray(Image.open(workdir / "one.png")))
+    # the generic-layer graphs have no frame pipe
+    r = run(["-i", "Assets/Sashimi.png", "-stream", "8", "-fp32"], workdir)
+    assert r.returncode != 0 and "fused fp16 kernels only" in r.stderr
+    # two instances share the device, each with its own three slots in flight
+    r = run(["-i", "Assets/Sashimi.png", "-stream", "64", "-devices", "0,0", "-o", "m.png"], workdir)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("stream on device 0: 32 frames") == 2 and "64 frames on 2 instances" in r.stdout
+    for k in range(2):
+        assert np.array_equal(np.asarray(Image.open(workdir / f"m.{k}.png")), np.asarray(Image.open(workdir / "one.png")))
+
+
+def test_stream_mode_full_hd(workdir):
+    """The throughput configuration from the C++ host: 1080p frames from page-locked host memory through a pass
+    of eight frames per slot, three slots in flight, back to host memory.  The picture equals the library's
+    single-frame result byte for byte; the rate is printed (and compared with bench.py's host-to-host leg in
+    the design notes, not asserted here beyond being a plausible number)."""
+    from conftest import synthetic_rgba
+    rgba = synthetic_rgba(1920, 1080, 1080)
+    Image.fromarray(rgba[..., :3]).save(workdir / "hd.png", compress_level=1)
+    r = subprocess.run([EXE, "-i", "hd.png", "-stream", "960", "-o", "hd_out.png"], cwd=workdir, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "output 3840x2160" in r.stdout and "stream on device 0: 960 frames" in r.stdout
+    whole, steady = _stream_rate(r.stdout)
+    print(r.stdout.splitlines()[-2])
+    assert whole > 100 and steady > 100
+    with S.SuperResolutionContext(1920, 1080) as ctx:
+        want = ctx.run(rgba)
+    assert np.array_equal(np.asarray(Image.open(workdir / "hd_out.png")), want[..., :3])
