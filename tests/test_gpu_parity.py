@@ -549,6 +549,35 @@ def test_conv_up1_tap_needs_one_pass():
         assert b"several passes" in ctx._L.srx_last_error()
 
 
+def test_conv_up1_tap_follows_the_frames_in_the_workspace():
+    """The tap returns a frame's tensor only while the workspace holds that frame: nothing before the first
+    upscale, the last pass's frames afterwards, and after srx_upscale_frames(first, count) the frames of that
+    range (workspace slot i = frame first + i)."""
+    w, h, batch = 70, 45, 5
+    frames = [synthetic_rgba(w, h, 7700 + i) for i in range(batch)]
+    want = []
+    with S.SuperResolutionContext(w, h) as one:
+        for f in frames:
+            one.run(f)
+            want.append(one.read_tensor(4))
+    assert not np.array_equal(want[0], want[3])
+    with S.SuperResolutionContext(w, h, batch=batch) as ctx:
+        with pytest.raises(S.SrxError):
+            ctx.read_tensor(4, frame=0)                    # nothing has run yet
+        for i, f in enumerate(frames):
+            ctx.upload_rgba8(i, f)
+        ctx.upscale()
+        for i in range(batch):
+            assert np.array_equal(ctx.read_tensor(4, frame=i), want[i])
+        ctx.upscale_frames(3, 2)
+        for i in (3, 4):
+            assert np.array_equal(ctx.read_tensor(4, frame=i), want[i])
+        for i in (0, 2):
+            with pytest.raises(S.SrxError) as e:
+                ctx.read_tensor(4, frame=i)
+            assert e.value.status == 5
+
+
 def test_stream_batch_of_64_full_hd_frames():
     """The frame-stream configuration at its real size: 64 resident 1080p frames per GPU (eight passes of
     eight frames, frame offsets up to 2.1 GB in the output image).  Frames 0, 9, 31 and 63 must equal the
