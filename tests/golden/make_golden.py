@@ -39,7 +39,29 @@ def windows(h, w, size=16):
     return {"tl": (0, 0, s), "br": (h - s, w - s, s), "c": ((h - s) // 2, (w - s) // 2, s)}
 
 
+def upsample_fixture():
+    """upsample_linear.npz: inputs and expected outputs of the generic upsample layer's LINEAR mode, from an
+    implementation that is not ours: torch-CPU float64 interpolate(mode="bilinear", align_corners=False), i.e.
+    half-pixel centres with the sample position clamped at the edges.  That DirectML's UPSAMPLE_2D LINEAR uses
+    this rule is taken from its documentation and cannot be run here: parity with DirectML stays unpinned."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(20261111)
+    out = {}
+    for k, (n, c, h, w, sx, sy) in enumerate([(2, 3, 5, 7, 3, 2), (1, 8, 9, 4, 2, 2), (1, 1, 1, 6, 4, 1), (1, 5, 6, 1, 1, 3), (1, 16, 11, 13, 2, 4)]):
+        x = rng.uniform(-1, 1, (n, c, h, w)).astype(np.float16)            # representable in both storage types
+        y = F.interpolate(torch.from_numpy(x.astype(np.float64)), scale_factor=(sy, sx), mode="bilinear", align_corners=False)
+        out[f"x{k}"] = x
+        out[f"scale{k}"] = np.array([sx, sy], np.int32)
+        out[f"y{k}"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "upsample_linear.npz"), **out)
+    print("upsample_linear.npz")
+
+
 def main():
+    if "--only-upsample" in sys.argv:
+        return upsample_fixture()
+    upsample_fixture()
     sro.build()
     W = sro.Weights(os.path.join(ASSETS, "weights.bin"))
 

@@ -151,6 +151,34 @@ def test_upsample_and_add_layers(layout):
     assert torch.equal(a, expect)
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_linear_upsample_against_torch_fixture(dtype, layout):
+    """LINEAR mode in both storage types against tests/golden/upsample_linear.npz (torch-CPU float64 bilinear,
+    align_corners=False, made by tests/golden/make_golden.py).  fp16: the kernel interpolates in fp32 and rounds
+    once, so the result is within half an fp16 ulp of the float64 value (|x| <= 1: 2^-11) plus fp32 noise."""
+    import os
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "upsample_linear.npz"))
+    td = torch.float16 if dtype == 0 else torch.float32
+    perm = (0, 2, 3, 1) if layout else (0, 1, 2, 3)
+    back = (0, 3, 1, 2) if layout else (0, 1, 2, 3)
+    k = 0
+    while f"x{k}" in fx:
+        x, (sx, sy), want = fx[f"x{k}"], fx[f"scale{k}"], fx[f"y{k}"]
+        n, c, H, W = x.shape
+        dx = torch.tensor(x.transpose(perm).copy(), dtype=td, device="cuda")
+        shape = (n, H * sy, W * sx, c) if layout else (n, c, H * sy, W * sx)
+        out = torch.full(shape, float("nan"), dtype=td, device="cuda")
+        S.layer_upsample2d(dtype, layout, dx.data_ptr(), (n, c, H, W), int(sx), int(sy), 1, out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().double().numpy().transpose(back)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= (2 ** -11 + 1e-5 if dtype == 0 else 1e-5), (k, dtype, layout)
+        k += 1
+    assert k == 5
+
+
 def test_layer_argument_errors():
     x = torch.zeros(64, device="cuda")
     with pytest.raises(S.SrxError):      # filter depth != input channels
