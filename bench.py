@@ -407,16 +407,19 @@ def main():
             launch_pixels = ctx.width * ctx.height * frames_per_launch
             achieved = FLOP_PER_LR_PIXEL[dom] * launch_pixels / dom_s / 1e12
             achieved_direct = FLOP_PER_LR_PIXEL_DIRECT[dom] * launch_pixels / dom_s / 1e12
-            traffic, traffic_note = None, "traffic: none committed for this configuration"
+            traffic, traffic_note, tj = None, "traffic: none committed for this configuration", {}
             tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if args.config == "stream" and os.path.exists(tp):
+            if os.path.exists(tp):
                 try:
                     tj = json.load(open(tp))
-                    traffic = tj.get(dom)
-                    traffic_note = ("traffic is NOT measured by this run: it is the HBM byte count per launch from the "
-                                    "committed rocprofv3 --pmc passes (profiles/traffic.json, " + tj.get("_measured", "date not recorded") + ")")
+                    entry = tj if args.config == "stream" else tj.get("tiles8k", {})
+                    traffic = entry.get(dom)
+                    if traffic is not None:
+                        traffic_note = ("traffic is NOT measured by this run: it is the HBM byte count per launch from the "
+                                        "committed rocprofv3 --pmc passes (profiles/traffic.json, " + entry.get("_measured", "date not recorded") +
+                                        ("" if args.config == "stream" else "; " + entry.get("_config", "")) + ")")
                 except Exception:
-                    traffic = None
+                    traffic, tj = None, {}
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_DENSE / 1e12,
                 "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_FP16_DENSE, 4), "traffic": traffic,
@@ -437,6 +440,11 @@ def main():
         if not dry and world == 1 and args.config == "stream":
             if not args.no_latency_leg:
                 out["latency_ms_single_frame"] = single_frame_latency(S, distinct[0], local_rank)
+                lat = tj.get("latency", {}) if not dry else {}
+                if all(k in lat for k in FLOP_PER_LR_PIXEL if k.startswith(("pack_", "conv4_conv5"))):
+                    out["latency_hbm_bytes_per_frame"] = {"pack_conv1_conv2_conv3_conv_up1": lat["pack_conv1_conv2_conv3_conv_up1"],
+                                                          "conv4_conv5_conv6_add_unorm": lat["conv4_conv5_conv6_add_unorm"],
+                                                          "note": "committed rocprofv3 --pmc passes of the batch-1 plan, not measured by this run (" + lat.get("_measured", "") + ")"}
             if not args.no_pcie_leg:
                 out["pcie_inclusive"] = pcie_inclusive(S, distinct, local_rank)
         parity_failed = False

@@ -79,8 +79,10 @@ void SuperResolutionX::LoadPipeline()
     ThrowIfFailed(hipGetDeviceCount(&count) == hipSuccess && count > 0, "no HIP device found");
     ThrowIfFailed(m_deviceIndex >= 0 && m_deviceIndex < count, "device index out of range");
     ThrowIfFailed(hipSetDevice(m_deviceIndex) == hipSuccess, "hipSetDevice failed");
+    // the stream of the single-image mode; the frame stream brings its own three (upload, compute, download)
     hipStream_t stream = nullptr;
-    ThrowIfFailed(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess, "hipStreamCreate failed");
+    if (!m_framesPerSlot)
+        ThrowIfFailed(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess, "hipStreamCreate failed");
     m_stream = stream;
 
     ThrowIfFailed(InitTensors(), "InitTensors failed");

@@ -1130,8 +1130,17 @@ srx_status srx_pipe_create(srx_ctx* c, uint32_t framesPerSlot, srx_pipe** out) t
         return fail(e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_HIP, msg);
     };
     hipError_t e;
-    for (hipStream_t* st : {&p->up, &p->comp, &p->down})
-        if ((e = hipStreamCreateWithFlags(st, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreateWithFlags");
+    // The copies of one slot must run beside the kernels of another, which they only do from different hardware
+    // queues.  The runtime deals a process's streams over a small pool of hardware queues per priority level (four
+    // by default), so in a process with other streams of its own the three streams of a pipe can come to share one,
+    // and then copies and kernels take turns (measured: 870 instead of 1540 1080p frames/s with ONE more stream
+    // in the process).  The copy streams are therefore created at the highest priority, which has a pool of its
+    // own; the compute stream stays at the default priority.
+    int leastPriority = 0, greatestPriority = 0;
+    if ((e = hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority)) != hipSuccess) return bail(e, "hipDeviceGetStreamPriorityRange");
+    if ((e = hipStreamCreateWithFlags(&p->comp, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreateWithFlags");
+    for (hipStream_t* st : {&p->up, &p->down})
+        if ((e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatestPriority)) != hipSuccess) return bail(e, "hipStreamCreateWithPriority");
     for (uint32_t s = 0; s < p->slots; ++s)
     {
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&p->hostIn[s]), p->inFrame * framesPerSlot, hipHostMallocDefault)) != hipSuccess)
@@ -1210,16 +1219,15 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot) try
         SRX_HIP(hipStreamWaitEvent(p->up, p->evComp[slot], 0));
         SRX_HIP(hipStreamWaitEvent(p->comp, p->evDown[slot], 0));
     }
+    // Both sides of every copy are contiguous (tightly packed host frames; ctx images with pitch = width x 4 and
+    // frames back to back), so each slot moves as ONE linear copy per direction: linear copies between page-locked
+    // and device memory go to the DMA engines, which run beside the kernels; rectangular ones may be done by a
+    // copy kernel, which waits for CUs behind the persistent kernels of the compute stream.
     if (p->inChannels == 3)
-    {
-        SRX_HIP(hipMemcpy2DAsync(p->devRgbIn[slot], p->inPitch, p->hostIn[slot], p->inPitch, p->inPitch,
-                                 size_t(c->height) * p->perSlot, hipMemcpyHostToDevice, p->up));
-    }
+        SRX_HIP(hipMemcpyAsync(p->devRgbIn[slot], p->hostIn[slot], p->inFrame * p->perSlot, hipMemcpyHostToDevice, p->up));
     else
-        for (uint32_t f = 0; f < p->perSlot; ++f)
-            SRX_HIP(hipMemcpy2DAsync(c->input.base + size_t(first + f) * c->input.frame, size_t(c->input.pitch),
-                                     p->hostIn[slot] + f * p->inFrame, p->inPitch, p->inPitch, c->height,
-                                     hipMemcpyHostToDevice, p->up));
+        SRX_HIP(hipMemcpyAsync(c->input.base + size_t(first) * c->input.frame, p->hostIn[slot], p->inFrame * p->perSlot,
+                               hipMemcpyHostToDevice, p->up));
     SRX_HIP(hipEventRecord(p->evUp[slot], p->up));
     SRX_HIP(hipStreamWaitEvent(p->comp, p->evUp[slot], 0));
     // The channel repacking runs on the compute stream: the fused kernels are persistent and fill
@@ -1234,15 +1242,10 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot) try
     SRX_HIP(hipEventRecord(p->evComp[slot], p->comp));
     SRX_HIP(hipStreamWaitEvent(p->down, p->evComp[slot], 0));
     if (p->outChannels == 3)
-    {
-        SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot], p->outPitch, p->devRgbOut[slot], p->outPitch, p->outPitch,
-                                 size_t(c->height) * 2 * p->perSlot, hipMemcpyDeviceToHost, p->down));
-    }
+        SRX_HIP(hipMemcpyAsync(p->hostOut[slot], p->devRgbOut[slot], p->outFrame * p->perSlot, hipMemcpyDeviceToHost, p->down));
     else
-        for (uint32_t f = 0; f < p->perSlot; ++f)
-            SRX_HIP(hipMemcpy2DAsync(p->hostOut[slot] + f * p->outFrame, p->outPitch,
-                                     c->output.base + size_t(first + f) * c->output.frame, size_t(c->output.pitch),
-                                     p->outPitch, size_t(c->height) * 2, hipMemcpyDeviceToHost, p->down));
+        SRX_HIP(hipMemcpyAsync(p->hostOut[slot], c->output.base + size_t(first) * c->output.frame, p->outFrame * p->perSlot,
+                               hipMemcpyDeviceToHost, p->down));
     SRX_HIP(hipEventRecord(p->evDown[slot], p->down));
     p->submitted[slot] = true;
     return SRX_OK;

@@ -477,7 +477,12 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     // multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
     const int maxSegs = height2 / 32 > 1 ? (height2 / 32 < 64 ? height2 / 32 : 64) : 1;
     long bestCost = 0;
-    for (int segs = 1; segs <= maxSegs; ++segs)
+#if SRX_DIAG
+    static const int forced = diagEnvInt("SRX_SEGS_HR", 0);      // a fixed number of row segments, for measurements
+#else
+    constexpr int forced = 0;
+#endif
+    for (int segs = forced > 0 ? forced : 1; segs <= (forced > 0 ? forced : maxSegs); ++segs)
     {
         StripPlan c = pl;
         c.segRows = ((height2 + segs - 1) / segs + 3) & ~3;
@@ -488,7 +493,7 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
         const int slots = gridFor(pairs, numCUs, 1);
         c.rounds = (pairs + slots - 1) / slots;
         c.cost = 100L * c.rounds * c.steps;
-        if (segs == 1 || c.cost < bestCost)
+        if (segs == 1 || forced > 0 || c.cost < bestCost)
         {
             bestCost = c.cost;
             pl = c;

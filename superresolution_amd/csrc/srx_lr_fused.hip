@@ -156,7 +156,8 @@ __device__ __forceinline__ void mfmaChain(f32x16& acc, Frags& pre, W&& w, RD&& r
 // channels, each with two activation fragments (16-pixel halves, reads 2k and 2k+1) and two filter
 // fragments w(k, output half), four MFMAs into four 16 x 16 accumulators.  piece(k) follows K-step k.
 // The chip holds a higher clock on this MFMA shape than on 32x32x16 at equal work.
-template <int NK, bool PIN, class W, class RD, class RDN, class PC>
+// SKIP (timing-only variants of SRX_DIAG builds): the last SKIP K-steps issue no MFMAs (wrong results).
+template <int NK, bool PIN, int SKIP = 0, class W, class RD, class RDN, class PC>
 __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, RD&& rd, RDN&& rdNext, PC&& piece)
 {
     constexpr int N = 2 * NK;
@@ -175,10 +176,14 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
             else return bq[R];
         };
         const f16x8 b0 = frag(IC<2 * K>{}), b1 = frag(IC<2 * K + 1>{});
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b0, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b1, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b1, acc[3], 0, 0, 0);
+        if constexpr (K < NK - SKIP)
+        {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b0, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<0>{}), b1, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w(kk, IC<1>{}), b1, acc[3], 0, 0, 0);
+        }
+        else asm volatile("" ::"v"(b0), "v"(b1));      // the fragments are still read
         piece(kk);
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     });
@@ -187,12 +192,16 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
 
 // EXP (variants of SRX_DIAG builds, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
 // epilogue pieces itself; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave
-// waits at the step barrier.  The shipping library instantiates EXP = 0 only.
+// waits at the step barrier; 8 = timing only, WRONG RESULTS: what a perfect levelling of the four SIMDs would
+// give: the conv3 and conv2 waves drop 20 MFMAs per step each (SIMDs 0-2: 4608 -> 4288 MFMA cycles) and the
+// conv1 wave issues 60 more on fragments it reads from the conv2 ring (SIMD 3: 3264 -> 4224), same total.
+// The shipping library instantiates EXP = 0 only.
 template <int EXP>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool PIN = (EXP & 1) == 0;
+    constexpr int LEVEL = (EXP & 8) ? 5 : 0;         // K-steps without MFMAs per step of a conv3 / conv2 wave
     unsigned long long clk0 = 0, ref0 = 0;
     if constexpr (SRX_DIAG != 0)
     {
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                                          finish(kk, accB, r3 - 1, 1);
                                          if constexpr (decltype(kk)::value == 16) biasAcc16(smem, kBiasC3 + nt * 32, q, accB);
                                      });
-                mfmaChain16<18, PIN>(accB, pre, w, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                mfmaChain16<18, PIN, LEVEL>(accB, pre, w, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
                                      [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
                                      [&](auto kk) {
                                          finish(kk, accA, r3, 0);
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                                         finish(kk, acc1, r2, 0, 1);
                                         if constexpr (decltype(kk)::value == 8) biasAcc16(smem, kBiasC2 + 32, q, acc1);
                                     });
-                mfmaChain16<9, PIN>(acc1, pre, wHi, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                mfmaChain16<9, PIN, LEVEL>(acc1, pre, wHi, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
                                     [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
                                     [&](auto kk) {
                                         finish(kk, acc0, r2, 1, 0);
@@ -574,6 +583,24 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                         }
                     }
                 }
+                if constexpr (LEVEL != 0)
+                {
+                    // timing only: 60 MFMAs on 30 fragments of the conv2 ring, results unused
+                    f32x4 dummy[4] = {};
+                    const char* src = smem + kA2Off + p16 * kA2Stride + q * 16;
+#pragma unroll
+                    for (int k = 0; k < 15; ++k)
+                    {
+                        const f16x8 b0 = *reinterpret_cast<const f16x8*>(src + (k % 3) * kA2Stride + (k / 3) * kA2Row);
+                        const f16x8 b1 = *reinterpret_cast<const f16x8*>(src + (16 + k % 3) * kA2Stride + (k / 3) * kA2Row);
+                        dummy[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[10 + k], b0, dummy[0], 0, 0, 0);
+                        dummy[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[11 + k], b0, dummy[1], 0, 0, 0);
+                        dummy[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[10 + k], b1, dummy[2], 0, 0, 0);
+                        dummy[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[11 + k], b1, dummy[3], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) asm volatile("" ::"v"(dummy[a]));
+                }
                 park(t + 3, lane, in0);
                 if (lane < 6) park(t + 3, 64 + lane, in1);
                 stepBarrier();
@@ -602,7 +629,12 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
     // rows, and what counts is rounds x steps (one workgroup per CU; segments at least 32 rows tall).
     const int maxSegs = height / 32 > 1 ? (height / 32 < 64 ? height / 32 : 64) : 1;
     long bestCost = 0;
-    for (int segs = 1; segs <= maxSegs; ++segs)
+#if SRX_DIAG
+    static const int forced = diagEnvInt("SRX_SEGS_LR", 0);      // a fixed number of row segments, for measurements
+#else
+    constexpr int forced = 0;
+#endif
+    for (int segs = forced > 0 ? forced : 1; segs <= (forced > 0 ? forced : maxSegs); ++segs)
     {
         StripPlan c = pl;
         c.segRows = (height + segs - 1) / segs;
@@ -612,7 +644,7 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
         const int slots = gridFor(c.items, numCUs, 1);
         c.rounds = (c.items + slots - 1) / slots;
         c.cost = 100L * c.rounds * c.steps;
-        if (segs == 1 || c.cost < bestCost)
+        if (segs == 1 || forced > 0 || c.cost < bestCost)
         {
             bestCost = c.cost;
             pl = c;
@@ -644,6 +676,7 @@ hipError_t PrepareFusedKernels()
     (void)lrDiag();
     if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<1>), kLrSmem);
     if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<4>), kLrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<8>), kLrSmem);
 #endif
     if (e == hipSuccess) e = PrepareHrFused();
     return e != hipSuccess ? e : PrepareZero();
@@ -684,6 +717,7 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     {
     case 1: hipLaunchKernelGGL(LrFusedKernel<1>, grid, block, kLrSmem, s, p); break;
     case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
+    case 8: hipLaunchKernelGGL(LrFusedKernel<8>, grid, block, kLrSmem, s, p); break;
     default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
     }
     clockProbeReport(probe, "LrFusedKernel", int(grid.x), s, (exp & 4) ? 1024 : 0);

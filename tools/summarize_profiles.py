@@ -4,6 +4,8 @@ profiles/: kernel-trace statistics, the bench line printed under rocprofv3, the 
 values per kernel, and the HBM traffic per launch that bench.py reports as roofline.traffic.
 
   python tools/summarize_profiles.py r01 [prefix]      # prefix of the files in profiles/, default = tag
+  python tools/summarize_profiles.py r03 --configs     # what tools/profile_configs.sh left: the tile and the
+                                                       # single-frame configurations, added to profiles/traffic.json
 """
 import csv
 import json
@@ -17,8 +19,43 @@ KERNELS = {"LR": "LrFusedKernel", "HR": "HrFusedKernel"}
 STAGE = {"LR": "pack_conv1_conv2_conv3_conv_up1", "HR": "conv4_conv5_conv6_add_unorm"}
 
 
+CONFIG_NOTES = {
+    "tiles8k": "one band of the 7680x4320 image as the tile partition runs it: 7680 x 554 input rows (540 + a 7-row halo on "
+               "either side), batch 1, one launch of each fused kernel",
+    "latency": "one 1920x1080 frame, batch 1 (strips cut into row segments), one launch of each fused kernel",
+}
+
+
+def configs(tag):
+    """Kernel statistics and HBM bytes per launch of the configurations profiled by tools/profile_configs.sh."""
+    dst = os.path.join(ROOT, "profiles")
+    tp = os.path.join(dst, "traffic.json")
+    traffic = json.load(open(tp))
+    for name, note in CONFIG_NOTES.items():
+        src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{name}")
+        shutil.copy(os.path.join(src, "stats", "run_kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+        shutil.copy(os.path.join(src, "stages.txt"), os.path.join(dst, f"{tag}_{name}_stage_times.txt"))
+        raw = {k: {} for k in KERNELS}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            values = {}
+            for row in csv.DictReader(open(os.path.join(src, "pmc_" + counter, "pmc_counter_collection.csv"))):
+                for k, kernel in KERNELS.items():
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        values.setdefault(k, []).append(float(row["Counter_Value"]))
+            for k, v in values.items():
+                raw[k][counter] = statistics.median(v)
+        entry = {"_config": note, "_measured": f"profile set {tag}, same corrections as the stream entries", "_raw_KiB": raw}
+        for k in KERNELS:
+            entry[STAGE[k]] = int(round((2 * raw[k]["FETCH_SIZE"] + raw[k]["WRITE_SIZE"]) * 1024))
+        traffic[name] = entry
+    json.dump(traffic, open(tp, "w"), indent=1)
+    print(json.dumps({k: traffic[k] for k in CONFIG_NOTES}, indent=1))
+
+
 def main():
     tag = sys.argv[1]
+    if "--configs" in sys.argv:
+        return configs(tag)
     prefix = sys.argv[2] if len(sys.argv) > 2 else tag
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
@@ -50,6 +87,10 @@ def main():
                "_raw_KiB": {k: {c: summary[k][c] for c in ("FETCH_SIZE", "WRITE_SIZE")} for k in KERNELS}}
     for k in KERNELS:
         traffic[STAGE[k]] = int(round((2 * summary[k]["FETCH_SIZE"] + summary[k]["WRITE_SIZE"]) * 1024))
+    tp = os.path.join(dst, "traffic.json")
+    if os.path.exists(tp):                  # keep the entries of the other configurations
+        old = json.load(open(tp))
+        traffic.update({k: old[k] for k in CONFIG_NOTES if k in old})
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
