@@ -173,8 +173,12 @@ srx_status srx_sync(srx_ctx* ctx, void* stream);
  * (the reference's effective layout, Content/SuperResolution.cpp:155-159);
  * fp32 with SRX_FLAG_FP32.  Needs SRX_FLAG_KEEP_TENSORS or a generic-layer
  * ctx, with one exception: SRX_T_CONV_UP1, the only tensor the two fused
- * kernels of the fast path pass through HBM, can be read from any ctx after
- * srx_upscale / srx_process when batch <= srx_frames_per_launch().
+ * kernels of the fast path pass through HBM, can be read from any ctx for the
+ * frames the workspace still holds: those of the last pass of the last
+ * srx_upscale / srx_process / srx_upscale_frames (all frames when batch <=
+ * srx_frames_per_launch(); with a larger batch the passes share one
+ * workspace).  Any other frame, a read before the first upscale included,
+ * fails with SRX_ERR_STATE; srx_upscale_static does not use the workspace.
  * `bytes` must be C*H*W*2 (*4 for fp32).  Synchronous. */
 srx_status srx_read_tensor(srx_ctx* ctx, uint32_t frame, int32_t tensor_id,
                            void* fp16_chw_out, size_t bytes);
@@ -232,8 +236,14 @@ srx_status  srx_device_info(const srx_ctx* ctx, int32_t* compute_units, int32_t*
  * frames that starts and ends in host memory.  The ctx's `batch` frames are
  * divided into slots of `frames_per_slot` frames (at least two slots).  Each
  * slot owns pinned host buffers for its input and output frames; a submitted
- * slot is copied to the GPU, upscaled and copied back on three HIP streams the
- * pipe owns, so the copies of one slot overlap the kernels of another.
+ * slot is copied to the GPU (one linear copy), upscaled and copied back (one
+ * linear copy) on three HIP streams the pipe owns, so the copies of one slot
+ * overlap the kernels of another.  The two copy streams are created at the
+ * device's highest stream priority: streams overlap only from different
+ * hardware queues, the runtime deals a process's streams over a few queues per
+ * priority level, and a caller with streams of its own at the default
+ * priority must not be able to push a copy stream onto the compute stream's
+ * queue.
  *
  *   srx_pipe_input  : the slot's pinned RGBA8 input frames (tightly packed:
  *                     pitch = in_w*4, frame stride = pitch*in_h) for the caller to fill
