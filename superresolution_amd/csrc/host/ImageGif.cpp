@@ -1,6 +1,3 @@
-// The LZW raster decoder below (Raster::emit / Raster::run) restates stbi__out_gif_code / stbi__process_gif_raster of
-// stb_image v2.30 (Sean Barrett and contributors; public domain / MIT No Attribution), so that GIFs decode to the bytes
-// the reference's loader gives.
 // GIF decoding (first image of the file) for the host program's image loader.
 //
 // The reference loads images through stb_image v2.30 (XUSG/Advanced/XUSGTextureLoader.h:17-32);
@@ -66,114 +63,131 @@ void colorTable(GifReader& r, uint8_t pal[256][4], int entries, int transparent)
     }
 }
 
-// The LZW raster of one image, drawn into `out` (RGBA screen) within the image's rectangle.
-struct Raster
+// ---- The raster of one image, in three separate passes.
+//
+// 1. gatherSubBlocks: the image data is a chain of sub-blocks (length byte + bytes, ended by a zero length or by the end
+//    of a file cut short); they are joined into one byte string.
+// 2. lzwIndices: the byte string is a variable-width LZW code stream (least significant bit first, at most 12 bits, clear
+//    code 2^n, end code 2^n + 1).  The dictionary keeps, per code, its prefix code, its last symbol and the LENGTH of its
+//    string, so a code's string is written back to front into its final place in the index buffer: no stack, no
+//    recursion.  Decoding stops at the end code, at the end of the data, or once the image's w * h indices are there.
+// 3. drawIndices: the indices go to the screen in raster order of the image's rectangle, row order 0, 8, 16 .. / 4, 12 .. /
+//    2, 6 .. / 1, 3 .. when interlaced; entries with alpha <= 128 (the transparent index) leave the screen as it is.
+// The accept / reject rules are those of the loader the reference uses (Common/stb_image.h:6684-6774), so that a file it
+// refuses is refused here: a stream must open with a clear code, a code may exceed the next free one by nothing, and the
+// dictionary is allowed to grow to 8192 entries before "too many codes".
+std::vector<uint8_t> gatherSubBlocks(GifReader& r)
 {
-    struct Code { int16_t prefix; uint8_t first, suffix; };
-    Code codes[8192];
-    uint8_t* out;
-    uint8_t* touched;
-    const uint8_t (*table)[4];
-    long lineSize, startX, startY, maxX, maxY, curX, curY, step;
-    int parse;
-
-    void emit(int code)
+    std::vector<uint8_t> data;
+    while (!r.atEnd())
     {
-        // the chain of prefixes is at most 4096 long: walk it with an explicit stack, oldest first
-        uint16_t stack[8192];
-        int n = 0;
-        for (int c = code; c >= 0 && n < 8192; c = codes[c].prefix) stack[n++] = uint16_t(c);
-        while (n > 0)
+        const int len = r.get8();
+        if (len == 0) break;
+        // a sub-block cut short by the end of the file reads as zeros up to its declared length, as the reference's
+        // loader reads it
+        for (int i = 0; i < len; ++i) data.push_back(uint8_t(r.get8()));
+    }
+    return data;
+}
+
+bool lzwIndices(const std::vector<uint8_t>& data, int minCodeSize, size_t wanted, std::vector<uint8_t>& indices, std::string& err)
+{
+    constexpr int kMaxCodes = 8192;
+    struct Entry { int prefix; uint16_t length; uint8_t first, last; };
+    std::vector<Entry> dict(kMaxCodes);
+    const int clearCode = 1 << minCodeSize, endCode = clearCode + 1;
+    for (int i = 0; i < clearCode; ++i) dict[size_t(i)] = Entry{-1, 1, uint8_t(i), uint8_t(i)};
+
+    int width = minCodeSize + 1, nextFree = clearCode + 2, previous = -1;
+    bool cleared = false;
+    uint32_t window = 0;
+    int windowBits = 0;
+    size_t at = 0;
+    indices.clear();
+    indices.reserve(wanted);
+    for (;;)
+    {
+        while (windowBits < width)
         {
-            const int c = stack[--n];
-            if (curY >= maxY) return;
-            const long idx = curX + curY;
-            touched[idx / 4] = 1;
-            const uint8_t* e = table[codes[c].suffix];
-            if (e[3] > 128)
-            {
-                out[idx] = e[2]; out[idx + 1] = e[1]; out[idx + 2] = e[0]; out[idx + 3] = e[3];
-            }
-            curX += 4;
-            if (curX >= maxX)
-            {
-                curX = startX;
-                curY += step;
-                while (curY >= maxY && parse > 0)
-                {
-                    step = (1L << parse) * lineSize;
-                    curY = startY + (step >> 1);
-                    --parse;
-                }
-            }
+            if (at >= data.size()) return true;                     // data exhausted: keep what was decoded
+            window |= uint32_t(data[at++]) << windowBits;
+            windowBits += 8;
+        }
+        const int code = int(window & ((1u << width) - 1u));
+        window >>= width;
+        windowBits -= width;
+
+        if (code == clearCode)
+        {
+            width = minCodeSize + 1;
+            nextFree = clearCode + 2;
+            previous = -1;
+            cleared = true;
+            continue;
+        }
+        if (code == endCode) return true;
+        if (code > nextFree) { err = "GIF: illegal code in raster"; return false; }
+        if (!cleared) { err = "GIF: no clear code"; return false; }
+        if (previous >= 0)
+        {
+            if (nextFree + 1 > kMaxCodes) { err = "GIF: too many codes"; return false; }
+            // new entry = string(previous) + first symbol of string(code); for code == nextFree that is string(previous)
+            // + its own first symbol
+            Entry& e = dict[size_t(nextFree)];
+            e.prefix = previous;
+            e.first = dict[size_t(previous)].first;
+            e.length = uint16_t(dict[size_t(previous)].length + 1);
+            e.last = code == nextFree ? e.first : dict[size_t(code)].first;
+            ++nextFree;
+        }
+        else if (code == nextFree) { err = "GIF: illegal code in raster"; return false; }
+
+        // the string of `code`, written from its last symbol back to its first; what exceeds the image is dropped
+        const size_t start = indices.size(), length = dict[size_t(code)].length;
+        const size_t keep = start >= wanted ? 0 : (length < wanted - start ? length : wanted - start);
+        indices.resize(start + keep);
+        size_t pos = length;
+        for (int c = code; c >= 0 && pos > 0; c = dict[size_t(c)].prefix)
+        {
+            --pos;
+            if (pos < keep) indices[start + pos] = dict[size_t(c)].last;
+        }
+        if ((nextFree & ((1 << width) - 1)) == 0 && nextFree <= 0x0fff) ++width;
+        previous = code;
+    }
+}
+
+// Row of the image that the k-th transmitted row of an interlaced image of `h` rows is.
+std::vector<int> interlacedRows(int h)
+{
+    std::vector<int> rows;
+    rows.reserve(size_t(h));
+    static const int first[4] = {0, 4, 2, 1}, step[4] = {8, 8, 4, 2};
+    for (int pass = 0; pass < 4; ++pass)
+        for (int y = first[pass]; y < h; y += step[pass]) rows.push_back(y);
+    return rows;
+}
+
+void drawIndices(const std::vector<uint8_t>& indices, const uint8_t (*table)[4], int x, int y, int w, int h, bool interlaced,
+                 int screenW, uint8_t* screen, uint8_t* touched)
+{
+    if (w <= 0 || h <= 0) return;
+    const std::vector<int> order = interlaced ? interlacedRows(h) : std::vector<int>();
+    for (size_t n = 0; n < indices.size(); ++n)
+    {
+        const int k = int(n / size_t(w)), col = int(n % size_t(w));
+        if (k >= h) break;
+        const int row = interlaced ? order[size_t(k)] : k;
+        const size_t pixel = size_t(y + row) * size_t(screenW) + size_t(x + col);
+        touched[pixel] = 1;
+        const uint8_t* e = table[indices[n]];                      // stored blue, green, red, alpha
+        if (e[3] > 128)
+        {
+            uint8_t* d = screen + pixel * 4;
+            d[0] = e[2]; d[1] = e[1]; d[2] = e[0]; d[3] = e[3];
         }
     }
-
-    bool run(GifReader& r, std::string& err)
-    {
-        const int lzwCs = r.get8();
-        if (lzwCs > 12) { err = "GIF: bad code size"; return false; }
-        const int clear = 1 << lzwCs;
-        bool first = true;
-        int codeSize = lzwCs + 1, codeMask = (1 << codeSize) - 1, avail = clear + 2, oldCode = -1, validBits = 0, len = 0;
-        unsigned bits = 0;
-        for (int i = 0; i < clear; ++i) codes[i] = Code{-1, uint8_t(i), uint8_t(i)};
-        for (;;)
-        {
-            if (validBits < codeSize)
-            {
-                if (len == 0)
-                {
-                    if (r.atEnd()) return true;          // a file cut short ends the raster
-                    len = r.get8();
-                    if (len == 0) return true;
-                }
-                --len;
-                bits |= unsigned(r.get8()) << validBits;
-                validBits += 8;
-                continue;
-            }
-            const int code = int(bits & unsigned(codeMask));
-            bits >>= codeSize;
-            validBits -= codeSize;
-            if (code == clear)
-            {
-                codeSize = lzwCs + 1;
-                codeMask = (1 << codeSize) - 1;
-                avail = clear + 2;
-                oldCode = -1;
-                first = false;
-            }
-            else if (code == clear + 1)
-            {
-                r.skip(size_t(len));
-                while ((len = r.get8()) > 0) r.skip(size_t(len));
-                return true;
-            }
-            else if (code <= avail)
-            {
-                if (first) { err = "GIF: no clear code"; return false; }
-                if (oldCode >= 0)
-                {
-                    if (avail + 1 > 8192) { err = "GIF: too many codes"; return false; }
-                    Code& p = codes[avail++];
-                    p.prefix = int16_t(oldCode);
-                    p.first = codes[oldCode].first;
-                    p.suffix = code == avail ? p.first : codes[code].first;
-                }
-                else if (code == avail) { err = "GIF: illegal code in raster"; return false; }
-                emit(code);
-                if ((avail & codeMask) == 0 && avail <= 0x0fff)
-                {
-                    ++codeSize;
-                    codeMask = (1 << codeSize) - 1;
-                }
-                oldCode = code;
-            }
-            else { err = "GIF: illegal code in raster"; return false; }
-        }
-    }
-};
+}
 
 }  // namespace
 
@@ -211,28 +225,21 @@ bool GifDecode(const std::vector<uint8_t>& file, int& width, int& height, int& c
         {
             const int x = r.get16(), y = r.get16(), w = r.get16(), h = r.get16();
             if (x + w > g.w || y + h > g.h) { err = "GIF: bad image descriptor"; return false; }
-            std::vector<Raster> holder(1);
-            Raster& ra = holder[0];
-            ra.out = pixels.data();
-            ra.touched = touched.data();
-            ra.lineSize = long(g.w) * 4;
-            ra.startX = long(x) * 4;
-            ra.startY = long(y) * ra.lineSize;
-            ra.maxX = ra.startX + long(w) * 4;
-            ra.maxY = ra.startY + long(h) * ra.lineSize;
-            ra.curX = ra.startX;
-            ra.curY = w == 0 ? ra.maxY : ra.startY;
             const int lflags = r.get8();
-            if (lflags & 0x40) { ra.step = 8 * ra.lineSize; ra.parse = 3; }
-            else { ra.step = ra.lineSize; ra.parse = 0; }
+            const uint8_t (*table)[4] = nullptr;
             if (lflags & 0x80)
             {
                 colorTable(r, g.lpal, 2 << (lflags & 7), (g.eflags & 1) ? g.transparent : -1);
-                ra.table = g.lpal;
+                table = g.lpal;
             }
-            else if (g.flags & 0x80) ra.table = g.pal;
+            else if (g.flags & 0x80) table = g.pal;
             else { err = "GIF: missing colour table"; return false; }
-            if (!ra.run(r, err)) return false;
+            const int minCodeSize = r.get8();
+            if (minCodeSize > 12) { err = "GIF: bad code size"; return false; }
+            const std::vector<uint8_t> data = gatherSubBlocks(r);
+            std::vector<uint8_t> indices;
+            if (!lzwIndices(data, minCodeSize, size_t(w) * size_t(h), indices, err)) return false;
+            drawIndices(indices, table, x, y, w, h, (lflags & 0x40) != 0, g.w, pixels.data(), touched.data());
             if (g.bgIndex > 0)
             {
                 g.pal[g.bgIndex][3] = 255;

@@ -380,3 +380,39 @@ def test_gif_smaller_than_its_screen(img, oracle, tmp_path):
     if R is not None:
         ref, c, r = ref_load(R, path)
         assert (c, r) == (ch, req) and np.array_equal(ref, got)
+
+
+def test_damaged_gifs_decode_as_the_reference_decoder_does(img, oracle, tmp_path):
+    """Truncated files and files with flipped bytes in the LZW data: accepted or refused as the reference's loader
+    does, and when accepted, with the same pixels (a raster cut short keeps what was decoded)."""
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref is not built here")
+    rng = np.random.default_rng(77)
+    accepted = refused = 0
+    for k, kw in enumerate([dict(interlace=0), dict(interlace=1), dict(transparency=2, interlace=0), dict(colors=200, w=64, h=40, interlace=0)]):
+        good = _gif(tmp_path, f"g{k}.gif", **kw).read_bytes()
+        start = good.index(b"\x2c", 13)                     # image descriptor: damage only what follows it
+        for trial in range(60):
+            d = bytearray(good)
+            if trial % 3 == 0:
+                d = d[:int(rng.integers(start + 11, len(d)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    d[int(rng.integers(start + 10, len(d)))] = int(rng.integers(0, 256))
+            path = tmp_path / "damaged.gif"
+            path.write_bytes(bytes(d))
+            w, h, c, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            p = R.ref_load_image(str(path).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(r))
+            out = np.zeros((h.value or 1, w.value or 1, 4), np.uint8)
+            rc = img.srx_image_load(str(path).encode(), out.ctypes.data, out.nbytes) if p else img.srx_image_load(
+                str(path).encode(), np.zeros(1 << 20, np.uint8).ctypes.data, 1 << 20)
+            if not p:
+                assert rc != 0, (k, trial)
+                refused += 1
+                continue
+            ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, r.value)).copy()
+            R.ref_free(p)
+            assert rc == 0 and np.array_equal(out, ref), (k, trial, img.srx_image_last_error())
+            accepted += 1
+    assert accepted > 40 and refused > 10, (accepted, refused)
