@@ -279,3 +279,15 @@ def test_up1_phase_form_with_all_channels():
     # and under a tenth of the 2e-2 the path is specified to
     assert err < 3e-3, err
     assert np.abs(direct).max() > 4
+
+
+def test_diagnostic_build_exports_the_same_abi():
+    """libsrx_diag.so (make DIAG=1) is the same library plus diagnostics: every declared symbol is there too."""
+    import ctypes as C
+    from superresolution_amd import _capi
+    path = os.path.join(os.path.dirname(_capi.lib_path()), "libsrx_diag.so")
+    if not os.path.exists(path):
+        pytest.skip("the diagnostic library has not been built")
+    L = C.CDLL(path)
+    for name in _capi.SYMBOLS:
+        assert hasattr(L, name), name
