@@ -379,6 +379,62 @@ static void conv_up1_phases(const float* in, int C, int H, int W, const float* w
     free(tmp);
 }
 
+/* Row-shared form of the same operator: only the COLUMNS of the 5x5 filter are folded per output phase px
+ * (three column taps, each the sum of the 5x5 taps that read the same low-resolution column, rounded once to
+ * fp16); the five ROW taps stay as they are and read low-resolution row y + floor((py + i - 2) / 2).  The two
+ * output rows 2y and 2y + 1 then share the terms of row taps 0, 2, 4 and differ in where taps 1 and 3 read,
+ * which is how the fused GPU kernel evaluates conv_up1 (30 instead of 36 products per input pixel). */
+static void conv_up1_rowshared(const float* in, int C, int H, int W, const float* wt /*[O,C,5,5]*/,
+                               const float* bias, int O, int round16, float* out /*[O,2H,2W]*/)
+{
+    const size_t plane = (size_t)H * W;
+    const int H2 = 2 * H, W2 = 2 * W;
+    float* pw = (float*)malloc(sizeof(float) * (size_t)O * C * 15);
+    for (int px = 0; px < 2; ++px) {
+        for (int o = 0; o < O; ++o)
+            for (int c = 0; c < C; ++c)
+                for (int i = 0; i < 5; ++i) {
+                    double s[3] = {0};
+                    for (int j = 0; j < 5; ++j) s[phase_tap(px, j)] += (double)wt[((o * C + c) * 5 + i) * 5 + j];
+                    for (int t = 0; t < 3; ++t) {
+                        const float v = (float)s[t];
+                        pw[((o * C + c) * 5 + i) * 3 + t] = round16 ? round_f16(v) : v;
+                    }
+                }
+#pragma omp parallel
+        {
+            float* acc = (float*)malloc(sizeof(float) * (size_t)W);
+#pragma omp for collapse(2) schedule(static)
+            for (int o = 0; o < O; ++o)
+                for (int y2 = 0; y2 < H2; ++y2) {
+                    const int y = y2 >> 1, py = y2 & 1;
+                    for (int x = 0; x < W; ++x) acc[x] = bias ? bias[o] : 0.0f;
+                    for (int c = 0; c < C; ++c)
+                        for (int i = 0; i < 5; ++i) {
+                            const int yy = y + phase_tap(py, i) - 1;
+                            if (yy < 0 || yy >= H) continue;
+                            const float* row = in + c * plane + (size_t)yy * W;
+                            for (int t = 0; t < 3; ++t) {
+                                const float wv = pw[((o * C + c) * 5 + i) * 3 + t];
+                                const int dx = t - 1;
+                                const int x0 = dx < 0 ? -dx : 0;
+                                const int x1 = dx > 0 ? W - dx : W;
+                                for (int x = x0; x < x1; ++x) acc[x] += row[x + dx] * wv;
+                            }
+                        }
+                    float* dst = out + ((size_t)o * H2 + y2) * W2 + px;
+                    for (int x = 0; x < W; ++x) {
+                        float v = acc[x];
+                        if (!(v > 0.0f)) v = (v == v) ? 0.0f : v;
+                        dst[2 * x] = round16 ? round_f16(v) : v;
+                    }
+                }
+            free(acc);
+        }
+    }
+    free(pw);
+}
+
 /* ------------------------------------------------------------------------ */
 /* the model                                                                */
 /* ------------------------------------------------------------------------ */
@@ -493,6 +549,8 @@ int sro_run(sro_model* m, const uint8_t* rgba, int w, int h, size_t pitch,
             upsample2x(cur, L->C, h, w, up);
             conv2d(up, L->C, H2, W2, L->w, L->b, L->O, L->k, L->relu, r16, o);
             free(up);
+        } else if (m->up1_mode == 2) {
+            conv_up1_rowshared(cur, L->C, h, w, L->w, L->b, L->O, r16, o);
         } else {
             conv_up1_phases(cur, L->C, h, w, L->w, L->b, L->O, r16, o);
         }

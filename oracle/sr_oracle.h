@@ -82,8 +82,11 @@ enum {
  * up1_mode: 0 = conv_up1 exactly as the reference graph states it (5x5 on the
  *            NN-upsampled tensor); 1 = the algebraically equivalent four-phase
  *            3x3 form on the low-resolution tensor with phase weights summed in
- *            double and rounded once to fp16 (a restatement of the fast HIP
- *            formulation, used to measure what that rounding costs). */
+ *            double and rounded once to fp16 (the layer-wise HIP kernels'
+ *            formulation, used to measure what that rounding costs); 2 = the
+ *            row-shared form the fused HIP kernel evaluates: only the columns of
+ *            the 5x5 filter are folded per output phase (summed in double, rounded
+ *            once to fp16), the five row taps are used as they are. */
 typedef struct sro_model sro_model;
 sro_model* sro_model_create(const sro_weights* w, int dtype, int up1_mode);
 void       sro_model_destroy(sro_model* m);

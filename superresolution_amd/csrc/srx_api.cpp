@@ -146,7 +146,7 @@ struct srx_ctx
     float* bias[srx::kNumConvLayers] = {};
     uint16_t* wpk6Rows16 = nullptr;          // conv6 as row-streaming 16x16x32 fragments (fused kernel)
     uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
-    uint16_t* wpkK32[6] = {};                // conv2, conv3, conv_up1 phases, conv4, conv5 as 16x16x32 fragments (fused kernels), by layer
+    uint16_t* wpkK32[6] = {};                // conv2, conv3, conv_up1 (row-shared form), conv4, conv5 as 16x16x32 fragments (fused kernels), by layer
     float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
 
@@ -231,7 +231,7 @@ srx_status uploadWeights(srx_ctx* c)
     for (int l = 1; l <= 5; ++l)
     {
         const uint32_t* sz = kConvLayers[l].sizes;
-        const std::vector<uint16_t> packed = l == 3 ? PackConvUp1PhasesK32(c->folded.filter[l])
+        const std::vector<uint16_t> packed = l == 3 ? PackConvUp1RowSharedK32(c->folded.filter[l])
                                                     : PackConv3x3K32(c->folded.filter[l], int(sz[0]), int(sz[1]), true);
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
@@ -931,7 +931,7 @@ srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, siz
     const uint32_t* sz = srx::kConvLayers[layer].sizes;
     const std::vector<uint16_t> packed =
         layer == 0 ? srx::PackConv1Rows8(folded.filter[0])
-        : layer == 3 ? srx::PackConvUp1PhasesK32(folded.filter[3])
+        : layer == 3 ? srx::PackConvUp1RowSharedK32(folded.filter[3])
         : layer <= 5 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]), true)
                      : srx::PackConv6Rotating(folded.filter[6]);
     if (n) *n = packed.size();

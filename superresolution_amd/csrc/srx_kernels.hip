@@ -326,7 +326,9 @@ namespace dev {
 
 namespace {
 std::mutex g_launchStateMutex;
+#if SRX_DIAG
 constexpr int kMaxDevices = 64, kProbeBlocks = 4096;
+#endif
 }
 
 #if SRX_DIAG

@@ -8,12 +8,20 @@
 // and runs chains of MFMAs over tiles of 32 pixels x 32 outputs, one 1-KiB
 // ds_read_b128 of activations per 32 cycles of MFMA (v_mfma_f32_16x16x32_f16, four 16 x 16
 // accumulators per tile; conv1 uses v_mfma_f32_32x32x16_f16):
-//     waves 0-3  conv_up1, output phase = wave   2 chains of 72 MFMAs per step
+//     waves 0-3  conv_up1, 16 of the 32 outputs of one column phase   2 chains of 60 MFMAs per step
 //     waves 4-5  conv3, 32 of the 64 outputs     2 chains of 72
 //     wave  6    conv2, all 64 outputs           4 chains of 36
 //     wave  7    conv1 + the input row loader    3 chains of 10 (32x32x16)
-// Waves w and w+4 share a SIMD, so every SIMD has 4608 MFMA cycles of work per step (3264 on
+// Waves w and w+4 share a SIMD, so every SIMD has 4224 MFMA cycles of work per step (2880 on
 // the last pair).
+//
+// conv_up1 (a 5x5 filter on the nearest-neighbour-upsampled tensor) is evaluated on the low-resolution tensor in
+// the row-shared form.  Per output column phase px the five filter columns fold into three column taps (sums of the
+// taps that read the same input column, PackConvUp1RowSharedK32); the five filter rows stay apart.  With
+//     S(y) = row0 x[y-1] + row2 x[y] + row4 x[y+1]      T(y) = row1 x[y-1] + row3 x[y]
+// the two output rows that input row y makes are out(2y) = S(y) + T(y) and out(2y+1) = S(y) + T(y+1).  A wave walks
+// the rows downwards, so T(y+1), accumulated beside S(y) from the same activation fragments, is the next step's
+// T(y): it stays in the wave's registers and each step costs 30 instead of 36 products per input pixel and phase.
 //
 // Software pipeline.  A chain's results are converted and stored while the NEXT
 // chain of the same wave runs, a few instructions in each gap between its MFMAs,
@@ -81,6 +89,7 @@ template <int N, class F>
 __device__ __forceinline__ void forEach(F&& f) { forEachIdx(f, std::make_integer_sequence<int, N>{}); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Slot of row r in a ring of five rows (r >= -5000).  The value is made opaque so that the compiler
 // cannot distribute the multiplication by the row size over it: ring addresses then stay a VGPR base
@@ -112,6 +121,16 @@ __device__ __forceinline__ f16x4 reluHalf4(const f32x4& acc)
 {
     const f16x4 v = to_half4(acc[0], acc[1], acc[2], acc[3]);
     return __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
+}
+
+// a + b as two packed fp32 additions (left to itself the compiler splits most of these into four scalar ones).
+__device__ __forceinline__ f32x4 addPacked(const f32x4& a, const f32x4& b)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // Initial accumulators of a 32-pixel x 32-output tile held as four 16 x 16 tiles (index = 2 * pixel
@@ -190,6 +209,57 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
     pre = nxt;
 }
 
+// One tile (32 pixels x 16 outputs) of conv_up1 in the row-shared form: 18 K-steps k = (input row slot, column tap,
+// channel half), two activation fragments each (16-pixel halves).  wS(k) multiplies into S; the K-steps of the
+// second and third input row (k >= 6) also multiply wT(k) into T: 12 + 48 MFMAs.  The K-steps are issued in the order
+// kUpOrder, every third one a two-MFMA step of the first input row, so that the fragments a step waits for were
+// requested at least six MFMAs earlier wherever the chain stands (a wave is often alone on its SIMD at the end of a
+// step, and then nothing else hides LDS latency).  Position P of the chain: K-step kUpOrder[P], reads 2P and 2P + 1.
+// S starts from `initS` (the bias) and T from zero, as the C operand of their first MFMA: no accumulator is
+// initialised by a vector instruction.
+__device__ constexpr int kUpOrder[18] = {6, 7, 0, 8, 9, 1, 10, 11, 2, 12, 13, 3, 14, 15, 4, 16, 17, 5};
+
+template <bool PIN, class WS, class WT, class RD, class RDN, class PC>
+__device__ __forceinline__ void upChain(f32x4 (&accS)[2], f32x4 (&accT)[2], const f32x4& initS, Frags& pre, WS&& wS, WT&& wT, RD&& rd,
+                                        RDN&& rdNext, PC&& piece)
+{
+    constexpr int NK = 18, N = 2 * NK;
+    f16x8 bq[N];
+    Frags nxt;
+    forEach<NK>([&](auto pp) {
+        constexpr int P = decltype(pp)::value, K = kUpOrder[P];
+        forEach<2>([&](auto hh) {
+            constexpr int R = 2 * P + decltype(hh)::value;
+            if constexpr (R + kAhead < N) bq[R + kAhead] = rd(IC<R + kAhead>{});
+            else nxt.v[R + kAhead - N] = rdNext(IC<R + kAhead - N>{});
+        });
+        const auto frag = [&](auto rr) -> f16x8 {
+            constexpr int R = decltype(rr)::value;
+            if constexpr (R < kAhead) return pre.v[R];
+            else return bq[R];
+        };
+        const f16x8 b0 = frag(IC<2 * P>{}), b1 = frag(IC<2 * P + 1>{});
+        if constexpr (P == 0)
+        {
+            static_assert(kUpOrder[0] >= 6, "the first step must start both accumulators");
+            accS[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wS(IC<K>{}), b0, initS, 0, 0, 0);
+            accT[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wT(IC<K>{}), b0, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            accS[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wS(IC<K>{}), b1, initS, 0, 0, 0);
+            accT[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wT(IC<K>{}), b1, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        }
+        else
+        {
+            accS[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wS(IC<K>{}), b0, accS[0], 0, 0, 0);
+            if constexpr (K >= 6) accT[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wT(IC<K>{}), b0, accT[0], 0, 0, 0);
+            accS[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wS(IC<K>{}), b1, accS[1], 0, 0, 0);
+            if constexpr (K >= 6) accT[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wT(IC<K>{}), b1, accT[1], 0, 0, 0);
+        }
+        piece(pp);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    });
+    pre = nxt;
+}
+
 // EXP (variants of SRX_DIAG builds, env SRX_EXP_LR): 1 = no scheduling pins, the compiler orders the
 // epilogue pieces itself; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave
 // waits at the step barrier; 8 = timing only, WRONG RESULTS: what a perfect levelling of the four SIMDs would
@@ -219,10 +289,10 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     // this wave's filter fragments, resident for the whole kernel
     f16x8 wreg[36];
     {
-        const f16x8* src = role == 0 ? p.wpkU + wave * 36 * 64
+        const f16x8* src = role == 0 ? p.wpkU + wave * 30 * 64
                          : role == 1 ? p.wpk3 + (wave - 4) * 36 * 64
                          : role == 2 ? p.wpk2 : p.wpk1;
-        const int n = role == 3 ? 10 : 36;
+        const int n = role == 3 ? 10 : (role == 0 ? 30 : 36);
 #pragma unroll
         for (int s = 0; s < 36; ++s) wreg[s] = src[(s < n ? s : 0) * 64 + lane];
         // make the loads land here: a load still pending at the loop would put a vmcnt wait in front
@@ -305,11 +375,12 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 
         if (role == 0)
         {
-            // ---- conv_up1, phase `wave`: row ru at step ru + 8, rows Y0 .. Y1-1, and one more step
-            // to finish the last tile
-            const int py = wave >> 1, pxp = wave & 1;
+            // ---- conv_up1, column phase pxp, outputs 16 oh .. 16 oh + 15: input row ru at step ru + 8 makes output
+            // rows 2 ru and 2 ru + 1, rows Y0 .. Y1-1; one step before that a pass over row Y0 - 1 leaves T(Y0) in the
+            // registers (its outputs are dropped), and one more step at the end finishes the last tile
+            const int pxp = wave & 1, oh = wave >> 1;
             const int laneRd = kA3Off + p16 * kA2Stride + q * 16;      // + pixel and tap offsets
-            // A lane holds 8 consecutive channels of one pixel (16 B of an a4 row): channels 8q .. 8q+7.
+            // A lane holds 4 consecutive channels of one pixel (8 B of an a4 row): channels 16 oh + 4q .. + 3.
             // Lanes that own no pixel get an offset no buffer descriptor covers, so their stores are dropped.
             unsigned laneSt[4];
 #pragma unroll
@@ -317,76 +388,87 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 const int i = T * 16 + p16, col = X0 + i;
                 laneSt[T] = (i < kLrStrip && col < p.width)
-                                ? unsigned((2 * col + pxp) * 64 + q * 16) : 0xC0000000u;
+                                ? unsigned((2 * col + pxp) * 64 + oh * 32 + q * 8) : 0xC0000000u;
             }
             const long rowBytes = long(p.a4.pitch) * 64;
             char* a4f = reinterpret_cast<char*>(p.a4.base + f * p.a4.frame);
-            // finish a 32-pixel tile: ReLU, fp16, one 16-B store per 16-pixel half
-            unsigned d[4];
-            const auto finish = [&](auto kk, const f32x4 (&acc)[4], int row, int T32, bool rowValid) {
-                constexpr int K = decltype(kk)::value;
-                if constexpr (K == 1 || K == 9)
+            const f32x4 biasV = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + kBiasUp + oh * 16 + 4 * q);
+            const f32x4 zeroV = {0.0f, 0.0f, 0.0f, 0.0f};
+            // finish a tile: per 16-pixel half and output row parity, S + T, ReLU, fp16 and one 8-B store; then T(y+1)
+            // becomes the next row's T(y) (the next chain of the tile starts its accumulators anew)
+            unsigned d[2];
+            const auto finish = [&](auto kk, f32x4 (&accS)[2], f32x4 (&accTn)[2], f32x4 (&accTp)[2], int row, int T32, bool rowValid) {
+                // positions 3, 4 | 6, 7 | 9, 10 | 12, 13 of the running chain (four-MFMA steps): convert, then store
+                constexpr int P = decltype(kk)::value;
+                if constexpr (P >= 3 && P <= 13 && P % 3 != 2)
                 {
-                    constexpr int half = K == 1 ? 0 : 1;
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch)
+                    constexpr int part = P / 3 - 1, half = part >> 1, py = part & 1;
+                    if constexpr (P % 3 == 0)
                     {
-                        const f16x4 v = reluHalf4(acc[half * 2 + ch]);
+                        const f16x4 v = reluHalf4(addPacked(accS[half], py ? accTn[half] : accTp[half]));
                         const uint2 u = *reinterpret_cast<const uint2*>(&v);
-                        d[2 * ch] = u.x;
-                        d[2 * ch + 1] = u.y;
+                        d[0] = u.x;
+                        d[1] = u.y;
+                    }
+                    else
+                    {
+                        // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                            a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs, int(laneSt[T32 * 2 + half]), 0, 0);
                     }
                 }
-                if constexpr (K == 5 || K == 13)
-                {
-                    constexpr int half = K == 5 ? 0 : 1;
-                    // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[0], d[1], d[2], d[3]}, rs, int(laneSt[T32 * 2 + half]), 0, 0);
-                }
             };
-            // read r of a chain: K-step r / 2 = (tap, channel half), 16-pixel half r % 2 of the 32-pixel tile
+            // read r of a chain: K-step kUpOrder[r / 2] = (input row slot, column tap, channel half), 16-pixel half r % 2 of the tile
             const auto rdT = [&](auto rr, int T32, int c0, int c1, int c2) -> f16x8 {
                 constexpr int R = decltype(rr)::value;
-                constexpr int k = R / 2, half = R % 2, tap = k / 2, kc = k % 2, i = tap / 3, j = tap % 3;
+                constexpr int k = kUpOrder[R / 2], half = R % 2, tap = k / 2, kc = k % 2, i = tap / 3, j = tap % 3;
                 const int b = i == 0 ? c0 : (i == 1 ? c1 : c2);
                 return *reinterpret_cast<const f16x8*>(smem + b + (T32 * 32 + half * 16 + j) * kA2Stride + kc * 64);
             };
-            const auto w = [&](auto kk, auto hh) { return wreg[decltype(kk)::value * 2 + decltype(hh)::value]; };
+            const auto wS = [&](auto kk) { return wreg[decltype(kk)::value]; };
+            const auto wT = [&](auto kk) { return wreg[12 + decltype(kk)::value]; };       // fragments 18.. for K-steps 6..
 
             int t = t0;
-            for (; t < Y0 + 8; ++t) stepBarrier();
-            f32x4 accA[4], accB[4];
-            biasAcc16(smem, kBiasUp, q, accA);
-            biasAcc16(smem, kBiasUp, q, accB);
+            for (; t < Y0 + 7; ++t) stepBarrier();
+            // S of the two tiles, and two T sets per tile that take turns by row: the set that accumulates T(y+1) in
+            // one step is the T(y) of the next, and the other one starts anew (the row loop is unrolled by two so that
+            // no register is copied)
+            f32x4 sA[2] = {biasV, biasV}, sB[2] = {biasV, biasV};
+            f32x4 tA[2][2] = {{zeroV, zeroV}, {zeroV, zeroV}}, tB[2][2] = {{zeroV, zeroV}, {zeroV, zeroV}};
             Frags pre;
             {
-                const int b0 = laneRd + slot5(Y0 - 1) * kA2Row;
-                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b0, b0, b0); });
+                // the first fragments of a chain come from the middle input row (kUpOrder): row Y0 - 1 of the pass over Y0 - 1
+                const int b1 = laneRd + slot5(Y0 - 1) * kA2Row;
+                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b1, b1, b1); });
             }
-            for (int ru = Y0; ru < Y1; ++ru, ++t)
-            {
+            const auto rowStep = [&](int ru, f32x4 (&tpA)[2], f32x4 (&tnA)[2], f32x4 (&tpB)[2], f32x4 (&tnB)[2]) {
                 const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
                           b2 = laneRd + slot5(ru + 1) * kA2Row;
-                // tile 0; finishes tile 1 of the previous row
-                mfmaChain16<18, PIN>(accA, pre, w, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
-                                     [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
-                                     [&](auto kk) {
-                                         finish(kk, accB, ru - 1, 1, ru - 1 >= Y0);
-                                         if constexpr (decltype(kk)::value == 15) biasAcc16(smem, kBiasUp, q, accB);
-                                     });
+                // tile 0; finishes tile 1 of the previous row, whose T(y+1) is this row's T(y) of that tile
+                upChain<PIN>(sA, tnA, biasV, pre, wS, wT, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
+                             [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                             [&](auto kk) { finish(kk, sB, tpB, tnB, ru - 1, 1, ru - 1 >= Y0); });
                 // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
-                // first fragments come from row ru (slot b1)
-                mfmaChain16<18, PIN>(accB, pre, w, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
-                                     [&](auto rr) { return rdT(rr, 0, b1, b1, b1); },
-                                     [&](auto kk) {
-                                         finish(kk, accA, ru, 0, true);
-                                         if constexpr (decltype(kk)::value == 15) biasAcc16(smem, kBiasUp, q, accA);
-                                     });
+                // first fragments come from its middle input row, ru + 1 (slot b2)
+                upChain<PIN>(sB, tnB, biasV, pre, wS, wT, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
+                             [&](auto rr) { return rdT(rr, 0, b2, b2, b2); },
+                             [&](auto kk) { finish(kk, sA, tnA, tpA, ru, 0, ru >= Y0); });
                 stepBarrierReader();
+            };
+            int ru = Y0 - 1;
+            for (; ru + 1 < Y1; ru += 2, t += 2)
+            {
+                rowStep(ru, tA[0], tA[1], tB[0], tB[1]);
+                rowStep(ru + 1, tA[1], tA[0], tB[1], tB[0]);
             }
-            forEach<14>([&](auto kk) { finish(kk, accB, Y1 - 1, 1, true); });
+            if (ru < Y1)
+            {
+                rowStep(ru, tA[0], tA[1], tB[0], tB[1]);
+                ++t;
+                forEach<14>([&](auto kk) { finish(kk, sB, tB[1], tB[0], Y1 - 1, 1, true); });
+            }
+            else forEach<14>([&](auto kk) { finish(kk, sB, tB[0], tB[1], Y1 - 1, 1, true); });
             stepBarrier();
             for (++t; t <= tEnd; ++t) stepBarrier();
         }

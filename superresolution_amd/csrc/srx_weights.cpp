@@ -484,16 +484,49 @@ std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout
     return out;
 }
 
-std::vector<uint16_t> PackConvUp1PhasesK32(const std::vector<uint16_t>& oihw)
+std::vector<uint16_t> ConvUp1ColumnFilters(const std::vector<uint16_t>& oihw)
 {
-    const std::vector<uint16_t> phases = ConvUp1PhaseFilters(oihw);
-    std::vector<uint16_t> out;
-    for (int p = 0; p < 4; ++p)
+    constexpr int O = 32, C = 64;
+    std::vector<uint16_t> out(size_t(2) * O * C * 5 * 3, 0);
+    for (int px = 0; px < 2; ++px)
+        for (int o = 0; o < O; ++o)
+            for (int c = 0; c < C; ++c)
+                for (int i = 0; i < 5; ++i)
+                {
+                    double sum[3] = {};
+                    for (int j = 0; j < 5; ++j)
+                        sum[PhaseTap(px, j)] += static_cast<double>(ML::Float16ToFloat32(oihw[((size_t(o) * C + c) * 5 + i) * 5 + j]));
+                    for (int t = 0; t < 3; ++t)
+                        out[((((size_t(px) * O + o) * C + c) * 5 + i) * 3) + t] = ML::Float32ToFloat16(static_cast<float>(sum[t]));
+                }
+    return out;
+}
+
+std::vector<uint16_t> PackConvUp1RowSharedK32(const std::vector<uint16_t>& oihw)
+{
+    constexpr int O = 32, C = 64, kFrags = 30;
+    const std::vector<uint16_t> cols = ConvUp1ColumnFilters(oihw);
+    std::vector<uint16_t> out(size_t(4) * kFrags * 64 * 8, 0);
+    for (int wave = 0; wave < 4; ++wave)
     {
-        const std::vector<uint16_t> one(phases.begin() + size_t(p) * 32 * 64 * 9,
-                                        phases.begin() + size_t(p + 1) * 32 * 64 * 9);
-        const std::vector<uint16_t> packed = PackConv3x3K32(one, 32, 64, true);
-        out.insert(out.end(), packed.begin(), packed.end());
+        const int px = wave & 1, oh = wave >> 1;
+        for (int f = 0; f < kFrags; ++f)
+        {
+            // S fragments 0..17: row taps 0, 2, 4 (input rows y-1, y, y+1); T fragments 18..29: row taps 1, 3
+            // (input rows y, y+1 as seen from output row 2y+1)
+            const int g = f < 18 ? f : f - 18;
+            const int rowSlot = g / 6, j = (g % 6) / 2, kc = g % 2;
+            const int i = f < 18 ? 2 * rowSlot : 2 * rowSlot + 1;
+            for (int lane = 0; lane < 64; ++lane)
+            {
+                const int o = oh * 16 + (lane & 15), q = lane >> 4;
+                for (int jj = 0; jj < 8; ++jj)
+                {
+                    const int c = kc * 32 + 8 * q + jj;
+                    out[((size_t(wave) * kFrags + f) * 64 + lane) * 8 + jj] = cols[((((size_t(px) * O + o) * C + c) * 5 + i) * 3) + j];
+                }
+            }
+        }
     }
     return out;
 }

