@@ -218,24 +218,29 @@ __device__ __forceinline__ void mfmaChain16(f32x4 (&acc)[4], Frags& pre, W&& w, 
 // S starts from `initS` (the bias) and T from zero, as the C operand of their first MFMA: no accumulator is
 // initialised by a vector instruction.
 __device__ constexpr int kUpOrder[18] = {6, 7, 0, 8, 9, 1, 10, 11, 2, 12, 13, 3, 14, 15, 4, 16, 17, 5};
+constexpr int kUpAhead = 4;                      // LDS reads a conv_up1 chain keeps in flight ahead of their MFMAs
+struct UpFrags
+{
+    f16x8 v[kUpAhead];
+};
 
 template <bool PIN, class WS, class WT, class RD, class RDN, class PC>
-__device__ __forceinline__ void upChain(f32x4 (&accS)[2], f32x4 (&accT)[2], const f32x4& initS, Frags& pre, WS&& wS, WT&& wT, RD&& rd,
+__device__ __forceinline__ void upChain(f32x4 (&accS)[2], f32x4 (&accT)[2], const f32x4& initS, UpFrags& pre, WS&& wS, WT&& wT, RD&& rd,
                                         RDN&& rdNext, PC&& piece)
 {
     constexpr int NK = 18, N = 2 * NK;
     f16x8 bq[N];
-    Frags nxt;
+    UpFrags nxt;
     forEach<NK>([&](auto pp) {
         constexpr int P = decltype(pp)::value, K = kUpOrder[P];
         forEach<2>([&](auto hh) {
             constexpr int R = 2 * P + decltype(hh)::value;
-            if constexpr (R + kAhead < N) bq[R + kAhead] = rd(IC<R + kAhead>{});
-            else nxt.v[R + kAhead - N] = rdNext(IC<R + kAhead - N>{});
+            if constexpr (R + kUpAhead < N) bq[R + kUpAhead] = rd(IC<R + kUpAhead>{});
+            else nxt.v[R + kUpAhead - N] = rdNext(IC<R + kUpAhead - N>{});
         });
         const auto frag = [&](auto rr) -> f16x8 {
             constexpr int R = decltype(rr)::value;
-            if constexpr (R < kAhead) return pre.v[R];
+            if constexpr (R < kUpAhead) return pre.v[R];
             else return bq[R];
         };
         const f16x8 b0 = frag(IC<2 * P>{}), b1 = frag(IC<2 * P + 1>{});
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     if (tid < 192) reinterpret_cast<float*>(smem)[tid] = p.bias[tid];
 
     // EXP & 4 (with SRX_CLOCK): cycles each wave of the first 16 workgroups spends at the step barrier
-    unsigned long long waited = 0;
+    unsigned long long waited = 0, lapA = 0, lapB = 0;      // EXP & 4: ticks at the step barrier, in a step's first and second half
     const auto stepBarrier = [&] {
         if constexpr ((EXP & 4) != 0)
         {
@@ -396,8 +401,11 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             const f32x4 zeroV = {0.0f, 0.0f, 0.0f, 0.0f};
             // finish a tile: per 16-pixel half and output row parity, S + T, ReLU, fp16 and one 8-B store; then T(y+1)
             // becomes the next row's T(y) (the next chain of the tile starts its accumulators anew)
+            // `rowPtr` = the first of the tile's two output rows in a4 (kept as a running pointer: building it from the row
+            // number costs a 64-bit multiplication per store, and this wave's instruction count is what its step takes)
             unsigned d[2];
-            const auto finish = [&](auto kk, f32x4 (&accS)[2], f32x4 (&accTn)[2], f32x4 (&accTp)[2], int row, int T32, bool rowValid) {
+            __amdgpu_buffer_rsrc_t rs0, rs1;
+            const auto finish = [&](auto kk, f32x4 (&accS)[2], f32x4 (&accTn)[2], f32x4 (&accTp)[2], char* rowPtr, int T32, bool rowValid) {
                 // positions 3, 4 | 6, 7 | 9, 10 | 12, 13 of the running chain (four-MFMA steps): convert, then store
                 constexpr int P = decltype(kk)::value;
                 if constexpr (P >= 3 && P <= 13 && P % 3 != 2)
@@ -412,10 +420,14 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                     }
                     else
                     {
-                        // the row's descriptor: base = the a4 row, range = one row (none for a row outside the segment)
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                            a4f + (2 * row + py) * rowBytes, 0, rowValid ? int(rowBytes) : 0, 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs, int(laneSt[T32 * 2 + half]), 0, 0);
+                        // the rows' descriptors: base = the a4 row, range = one row (none for a row outside the segment)
+                        if constexpr (P == 4)
+                        {
+                            const int range = rowValid ? int(rowBytes) : 0;
+                            rs0 = __builtin_amdgcn_make_buffer_rsrc(rowPtr, 0, range, 0x00020000);
+                            rs1 = __builtin_amdgcn_make_buffer_rsrc(rowPtr + rowBytes, 0, range, 0x00020000);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, py ? rs1 : rs0, int(laneSt[T32 * 2 + half]), 0, 0);
                     }
                 }
             };
@@ -436,25 +448,57 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             // no register is copied)
             f32x4 sA[2] = {biasV, biasV}, sB[2] = {biasV, biasV};
             f32x4 tA[2][2] = {{zeroV, zeroV}, {zeroV, zeroV}}, tB[2][2] = {{zeroV, zeroV}, {zeroV, zeroV}};
-            Frags pre;
+            UpFrags pre;
             {
-                // the first fragments of a chain come from the middle input row (kUpOrder): row Y0 - 1 of the pass over Y0 - 1
-                const int b1 = laneRd + slot5(Y0 - 1) * kA2Row;
-                forEach<kAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b1, b1, b1); });
+                // the first fragments of a chain come from its first two input rows (kUpOrder): rows Y0 - 2 (not computed
+                // by this item, and used for values that are dropped) and Y0 - 1 of the pass over Y0 - 1
+                const int b0 = laneRd + slot5(Y0 - 2) * kA2Row, b1 = laneRd + slot5(Y0 - 1) * kA2Row;
+                forEach<kUpAhead>([&](auto rr) { pre.v[decltype(rr)::value] = rdT(rr, 0, b0, b1, b1); });
             }
+            char* outRow = a4f + 2 * long(Y0 - 1) * rowBytes;      // output row 2 ru of the row in flight
+            // ring offsets of input rows ru - 1, ru, ru + 1, rotated from step to step (no division per row)
+            int ring0 = slot5(Y0 - 2) * kA2Row, ring1 = slot5(Y0 - 1) * kA2Row, ring2 = slot5(Y0) * kA2Row;
             const auto rowStep = [&](int ru, f32x4 (&tpA)[2], f32x4 (&tnA)[2], f32x4 (&tpB)[2], f32x4 (&tnB)[2]) {
-                const int b0 = laneRd + slot5(ru - 1) * kA2Row, b1 = laneRd + slot5(ru) * kA2Row,
-                          b2 = laneRd + slot5(ru + 1) * kA2Row;
+                const int b0 = laneRd + ring0, b1 = laneRd + ring1, b2 = laneRd + ring2;
+                unsigned long long lap0 = 0;
+                if constexpr ((EXP & 4) != 0) lap0 = __builtin_amdgcn_s_memtime();
                 // tile 0; finishes tile 1 of the previous row, whose T(y+1) is this row's T(y) of that tile
                 upChain<PIN>(sA, tnA, biasV, pre, wS, wT, [&](auto rr) { return rdT(rr, 0, b0, b1, b2); },
                              [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
-                             [&](auto kk) { finish(kk, sB, tpB, tnB, ru - 1, 1, ru - 1 >= Y0); });
+                             [&](auto kk) { finish(kk, sB, tpB, tnB, outRow - 2 * rowBytes, 1, ru - 1 >= Y0); });
+                if constexpr ((EXP & 4) != 0)
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    lapA += now - lap0;
+                    lap0 = now;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // tile 1; finishes tile 0 of this row; its tail fetches tile 0 of the next row, whose
-                // first fragments come from its middle input row, ru + 1 (slot b2)
+                // first fragments come from its first two input rows, ru and ru + 1 (slots b1, b2): both complete
                 upChain<PIN>(sB, tnB, biasV, pre, wS, wT, [&](auto rr) { return rdT(rr, 1, b0, b1, b2); },
-                             [&](auto rr) { return rdT(rr, 0, b2, b2, b2); },
-                             [&](auto kk) { finish(kk, sA, tnA, tpA, ru, 0, ru >= Y0); });
+                             [&](auto rr) { return rdT(rr, 0, b1, b2, b2); },
+                             [&](auto kk) { finish(kk, sA, tnA, tpA, outRow, 0, ru >= Y0); });
+                if constexpr ((EXP & 4) != 0)
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    lapB += __builtin_amdgcn_s_memtime() - lap0;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                outRow += 2 * rowBytes;
+                ring0 = ring1;
+                ring1 = ring2;
+                ring2 = ring2 + kA2Row == 5 * kA2Row ? 0 : ring2 + kA2Row;
                 stepBarrierReader();
+            };
+            // The packed additions of `finish` are inline assembly, which the compiler's hazard recogniser does not look
+            // into: they must not read an accumulator before the MFMA that wrote it has retired.  Inside the loop they read
+            // what the chain before the running one wrote (at least ten MFMAs earlier); after the loop the last tile is
+            // finished right behind its last MFMA, hence the explicit wait states.
+            const auto mfmaResultsVisible = [] {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             };
             int ru = Y0 - 1;
             for (; ru + 1 < Y1; ru += 2, t += 2)
@@ -466,9 +510,14 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
             {
                 rowStep(ru, tA[0], tA[1], tB[0], tB[1]);
                 ++t;
-                forEach<14>([&](auto kk) { finish(kk, sB, tB[1], tB[0], Y1 - 1, 1, true); });
+                mfmaResultsVisible();
+                forEach<14>([&](auto kk) { finish(kk, sB, tB[1], tB[0], outRow - 2 * rowBytes, 1, true); });
             }
-            else forEach<14>([&](auto kk) { finish(kk, sB, tB[0], tB[1], Y1 - 1, 1, true); });
+            else
+            {
+                mfmaResultsVisible();
+                forEach<14>([&](auto kk) { finish(kk, sB, tB[0], tB[1], outRow - 2 * rowBytes, 1, true); });
+            }
             stepBarrier();
             for (++t; t <= tEnd; ++t) stepBarrier();
         }
@@ -691,7 +740,8 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     }
     if constexpr ((EXP & 4) != 0)
         if (p.clock && lane == 0 && blockIdx.x < 16)
-            for (int k = 0; k < 8; ++k) p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = k == 6 ? waited : 0;
+            for (int k = 0; k < 8; ++k)
+                p.clock[2 * gridDim.x + (blockIdx.x * 8 + wave) * 8 + k] = k == 6 ? waited : (k == 0 ? lapA : (k == 1 ? lapB : 0));
     if constexpr (SRX_DIAG != 0)
         if (p.clock && tid == 0)
         {
