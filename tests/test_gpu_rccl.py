@@ -32,6 +32,16 @@ def _rank_env():
     return e
 
 
+def _run_rank(cmd):
+    """Run `cmd` as the only rank of a job.  The rendezvous port is picked by binding port 0 and closing it, so now and
+    then another process takes it first: that one failure (EADDRINUSE, before any GPU work) is retried on a new port."""
+    for _ in range(3):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_rank_env(), timeout=300)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
+
+
 def test_sharding_helpers_over_nccl_world_size_1():
     code = textwrap.dedent(f"""
         import sys
@@ -71,17 +81,15 @@ def test_sharding_helpers_over_nccl_world_size_1():
         dist.destroy_process_group()
         print("rccl-ok")
     """)
-    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                       env=_rank_env(), timeout=300)
+    r = _run_rank([sys.executable, "-c", code])
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_bench_rank_under_a_launcher_uses_nccl():
     """bench.py as rank 0 of a one-rank job (the environment torch.distributed.run gives a rank): process group
     over nccl, barrier, max over ranks and the all-gather of the per-rank times, then the usual line."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--batch", "8", "--no-cpu-baseline", "--no-pcie-leg", "--no-latency-leg", "--stage-reps", "2"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_rank_env(), timeout=300)
+    r = _run_rank([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                   "--batch", "8", "--no-cpu-baseline", "--no-pcie-leg", "--no-latency-leg", "--stage-reps", "2"])
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
