@@ -6,9 +6,10 @@ and an fp16 rounding after every layer, and compared with oracle/sr_oracle.c on
 the bundled images.  The two differ only where a float64 sum and the oracle's
 fp32 running sum fall on different sides of an fp16 rounding boundary.
 
-Also reports what the four-phase 3x3 form of conv_up1 (up1_mode=1) costs against
-the direct form (up1_mode=0), which is the evidence behind the tolerance the HIP
-path is tested to.
+Also reports what the two folded forms of conv_up1 cost against the direct form
+(up1_mode=0): the four-phase 3x3 form of the layer-wise kernels (up1_mode=1) and the
+row-shared form of the fused kernel (up1_mode=2), which is the evidence behind the
+tolerance the HIP path is tested to.
 
 Run:  python oracle/crosscheck_torch.py
 """
@@ -63,6 +64,7 @@ def main():
     W = sro.Weights(os.path.join(ASSETS, "weights.bin"))
     direct = sro.Model(W, 0, 0)
     phases = sro.Model(W, 0, 1)
+    rowshared = sro.Model(W, 0, 2)
     for name in ["Sashimi128.png", "xiaoyao.png", "Sashimi.png"]:
         rgba = sro.load_rgba(os.path.join(ASSETS, name))
         o_img = direct.run(rgba, keep_tensors=True)
@@ -79,6 +81,11 @@ def main():
             d = np.abs(direct.tensor(tid) - phases.tensor(tid))
             print(f"   phases vs direct   {sro.TENSOR_NAMES[tid]:9s} max_abs {d.max():.3e}  mean_abs {d.mean():.3e}")
         print("   phases vs direct   image", compare_images(o_img, p_img))
+        r_img = rowshared.run(rgba, keep_tensors=True)
+        for tid in (sro.T_CONV_UP1, sro.T_CONV4, sro.T_CONV5, sro.T_CONV6, sro.T_OUTPUT):
+            d = np.abs(direct.tensor(tid) - rowshared.tensor(tid))
+            print(f"   row-shared vs direct {sro.TENSOR_NAMES[tid]:9s} max_abs {d.max():.3e}  mean_abs {d.mean():.3e}")
+        print("   row-shared vs direct image", compare_images(o_img, r_img))
 
 
 if __name__ == "__main__":
