@@ -204,8 +204,10 @@ srx_status srx_packed_weights(const char* weights_path, int32_t layer, uint16_t*
 
 /* Host-only: the fragments of layer 0..6 as the two FUSED kernels keep them in
  * registers (they differ from srx_packed_weights where a fused kernel uses
- * another MFMA shape or order): conv1 as ten K-steps by filter row; conv2,
- * conv3, the four conv_up1 phase filters, conv4 and conv5 as
+ * another MFMA shape or order): conv1 as ten K-steps by filter row; conv_up1 in
+ * its row-shared form, [wave = 2 * output half + column phase][30 fragments][lane][8]
+ * (fragments 0..17: filter rows 0, 2, 4 with the five filter columns folded into
+ * three column taps per phase; 18..29: filter rows 1, 3); conv2, conv3, conv4 and conv5 as
  * v_mfma_f32_16x16x32_f16 fragments [tile][kstep][output half][lane][8] (the
  * rows of the two halves are interleaved: row r of half h is output
  * 8 * (r >> 2) + 4 * h + (r & 3) of the tile, so that a lane's accumulators of
