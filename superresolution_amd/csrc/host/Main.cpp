@@ -4,14 +4,15 @@
 //
 //   srx_main [-i|-image <png>] [-uma] [-warp]        the reference's switches
 //            [-frames N] [-update] [-o out.png] [-device D] [-devices D0,D1,...] [-noshot]
-//            [-stream N [-slot F]]
+//            [-stream N [-slot F] [-shot]]
 // By default five frames are rendered with F11 "pressed" before the first one, so
 // a SuperResolutionX_<timestamp>.png appears like the reference's screen shot.
 //
 // -stream N runs the throughput configuration: N video frames (the input file, repeated) go from host
 // memory through the GPU and back in slots of F frames (default 8), three slots in flight (the
 // reference's FrameCount), and the program prints frames per second, host to host.  With -devices
-// every listed device runs its share of the N frames that way.
+// every listed device runs its share of the N frames that way.  -shot "presses" F11 before the first slot:
+// the screen shot is then the first frame of the slot that arrived last when the shot is due.
 //
 // -devices lists the GPUs of a multi-GPU run (the reference picks ONE adapter,
 // SuperResolutionX.cpp:76-117; frames are independent, so here every listed device gets
@@ -37,6 +38,7 @@ struct Options
     int frames = 5;
     int stream = 0, slot = 8;             // -stream N: frames of the throughput run; -slot F: frames per slot
     bool update = false, shot = true;
+    bool streamShot = false;              // -shot: F11 in stream mode too
     std::string outPath;
     std::vector<std::wstring> wide;       // what the class's own ParseCommandLineArgs sees
 };
@@ -58,6 +60,7 @@ void runInstance(const Options& opt, int device, int frames, bool update, bool s
         superResolutionX.OnInit();
         if (!quiet) std::printf("output %ux%u\n", superResolutionX.GetWidth(), superResolutionX.GetHeight());
         const int slots = (frames + opt.slot - 1) / opt.slot;
+        if (opt.streamShot && shot) superResolutionX.OnKeyUp(VK_F11);
         const auto s0 = std::chrono::steady_clock::now();
         for (int f = 0; f < slots; ++f)
         {
@@ -127,6 +130,7 @@ int main(int argc, char* argv[])
         if (sw && !strcasecmp(a + 1, "o") && i + 1 < argc) { opt.outPath = argv[++i]; continue; }
         if (sw && !strcasecmp(a + 1, "update")) { opt.update = true; continue; }
         if (sw && !strcasecmp(a + 1, "noshot")) { opt.shot = false; continue; }
+        if (sw && !strcasecmp(a + 1, "shot")) { opt.streamShot = true; continue; }
         opt.wide.emplace_back(a, a + std::strlen(a));
     }
 

@@ -77,6 +77,11 @@ bool SuperResolution::Init(void* stream, int device, uint32_t vendorId, const ch
     // Content/SuperResolution.cpp:155-163: NHWC tensors for the vendor that prefers them, fp32 tensors
     // without fp16 support.  Either choice runs the graph of generic layers; the default (fp16, any
     // other vendor) runs the fused MFMA kernels, whose internal layout is their own.
+    if (m_ctx)
+    {
+        cerr << "SuperResolution: already initialised" << endl;        // a second ctx would orphan the first
+        return false;
+    }
     uint32_t flags = SRX_FLAG_VERBOSE_WEIGHTS;
     if (!isFP16Supported) flags |= SRX_FLAG_FP32;
     if (vendorId == 0x10DE) flags |= SRX_FLAG_NHWC;
@@ -127,6 +132,11 @@ bool SuperResolution::loadInputImage(const char* fileName)
 bool SuperResolution::InitStream(int device, uint32_t vendorId, const char* fileName, bool isFP16Supported,
                                  uint32_t framesInFlight, uint32_t framesPerSlot)
 {
+    if (m_ctx)
+    {
+        cerr << "SuperResolution: already initialised" << endl;
+        return false;
+    }
     if (!isFP16Supported || vendorId == 0x10DE)
     {
         cerr << "SuperResolution: the frame stream runs the fused fp16 kernels only (no -fp32 / -nhwc)" << endl;

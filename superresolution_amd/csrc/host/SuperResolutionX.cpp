@@ -297,19 +297,28 @@ void SuperResolutionX::MoveToNextFrame()
             tm dateTime;
             const auto now = time(nullptr);
             if (localtime_r(&now, &dateTime) && strftime(timeStr, sizeof(timeStr), "%Y%m%d%H%M%S", &dateTime))
-                SaveImage((string("SuperResolutionX_") + timeStr + ".png").c_str(), &m_readBuffer, m_width, m_height,
-                          m_readBuffer.rowPitch);
+            {
+                const string name = string("SuperResolutionX_") + timeStr + ".png";
+                // stream mode has no read-back copy: the shot is the first frame of the slot that arrived last
+                if (m_framesPerSlot) SaveStreamFrame(name.c_str());
+                else SaveImage(name.c_str(), &m_readBuffer, m_width, m_height, m_readBuffer.rowPitch);
+            }
             m_screenShot = 0;
         }
         else ++m_screenShot;
     }
 }
 
-void SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
+bool SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
                                  uint32_t rowPitch, uint8_t comp)
 {
     assert(comp == 3 || comp == 4);
     const uint8_t* pData = pImageBuffer->pixels;
+    if (!pData)
+    {
+        cerr << "SaveImage: no picture has been read back yet" << endl;
+        return false;
+    }
 
     // strip the row pitch and (comp == 3) the alpha channel
     vector<uint8_t> imageData(size_t(comp) * w * h);
@@ -319,28 +328,37 @@ void SuperResolutionX::SaveImage(char const* fileName, const RenderTarget* pImag
                 imageData[(size_t(w) * i + j) * comp + k] = pData[size_t(rowPitch) * i + 4 * j + k];
 
     if (!srx::WritePng(fileName, int(w), int(h), comp, imageData.data(), 0))
+    {
         cerr << "SaveImage: " << srx::LastImageError() << endl;
-    else cout << "Saved " << fileName << endl;
+        return false;
+    }
+    cout << "Saved " << fileName << endl;
+    return true;
+}
+
+// Stream mode: the first frame of the slot that arrived last (RGB8, tightly packed, in the slot's page-locked buffer).
+bool SuperResolutionX::SaveStreamFrame(const char* fileName)
+{
+    if (!m_lastOutput)
+    {
+        cerr << "SaveImage: no slot has arrived yet" << endl;
+        return false;
+    }
+    if (!srx::WritePng(fileName, int(m_width), int(m_height), 3, m_lastOutput, 0))
+    {
+        cerr << "SaveImage: " << srx::LastImageError() << endl;
+        return false;
+    }
+    cout << "Saved " << fileName << endl;
+    return true;
 }
 
 bool SuperResolutionX::SaveFrame(const char* fileName)
 {
     WaitForGpu();
-    if (m_framesPerSlot)
-    {
-        // the first frame of the slot that arrived last: RGB8, tightly packed
-        if (!m_lastOutput) return false;
-        if (!srx::WritePng(fileName, int(m_width), int(m_height), 3, m_lastOutput, 0))
-        {
-            cerr << "SaveImage: " << srx::LastImageError() << endl;
-            return false;
-        }
-        cout << "Saved " << fileName << endl;
-        return true;
-    }
+    if (m_framesPerSlot) return SaveStreamFrame(fileName);
     const uint32_t last = (m_frameIndex + FrameCount - 1) % FrameCount;
-    SaveImage(fileName, &m_renderTargets[last], m_width, m_height, m_renderTargets[last].rowPitch);
-    return true;
+    return SaveImage(fileName, &m_renderTargets[last], m_width, m_height, m_renderTargets[last].rowPitch);
 }
 
 double SuperResolutionX::CalculateFrameStats(float* pTimeStep)

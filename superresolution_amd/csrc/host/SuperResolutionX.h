@@ -107,7 +107,8 @@ private:
     void WaitForGpu();
     void WaitForFrame(uint32_t index);
     void MoveToNextFrame();
-    void SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
+    bool SaveStreamFrame(const char* fileName);
+    bool SaveImage(char const* fileName, const RenderTarget* pImageBuffer, uint32_t w, uint32_t h,
                    uint32_t rowPitch, uint8_t comp = 3);
     double CalculateFrameStats(float* fTimeStep = nullptr);
 };

@@ -150,6 +150,14 @@ def test_stream_mode_small_image_equals_single_frame_path(workdir):
     assert r.returncode == 0, r.stderr
     assert "stream on device 0: 44 frames" in r.stdout            # whole slots: 11 x 4
     assert np.array_equal(np.asarray(Image.open(workdir / "s.png")), np.asarray(Image.open(workdir / "one.png")))
+    # F11 in stream mode: the shot is the first frame of a slot that has arrived
+    before = set(glob.glob(str(workdir / "SuperResolutionX_*.png")))
+    r = run(["-i", "Assets/Sashimi.png", "-stream", "24", "-slot", "4", "-shot"], workdir)
+    assert r.returncode == 0, r.stderr
+    shots = sorted(set(glob.glob(str(workdir / "SuperResolutionX_*.png"))) - before)
+    assert len(shots) == 1, (shots, r.stdout)
+    assert np.array_equal(np.asarray(Image.open(shots[0])), np.asarray(Image.open(workdir / "one.png")))
+    os.remove(shots[0])
     # the generic-layer graphs have no frame pipe
     r = run(["-i", "Assets/Sashimi.png", "-stream", "8", "-fp32"], workdir)
     assert r.returncode != 0 and "fused fp16 kernels only" in r.stderr
