@@ -249,6 +249,8 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # the host driver of these boxes only supports dmabuf IPC: RCCL needs this before the runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
