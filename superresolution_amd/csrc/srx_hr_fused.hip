@@ -1,9 +1,15 @@
 // gfx950 kernel: conv4 -> conv5 -> conv6 -> + NN2x(input) -> UNORM8, fused.
 //
-// A workgroup of eight waves (one per CU, 102 KB LDS) walks TWO strips of kHrStrip output columns
-// downwards, one row per step: waves 0-3 (group 0) own one strip, waves 4-7 (group 1) the next, each
-// with rolling windows of the two intermediate activations in its own LDS rings, so neither
-// intermediate touches HBM and no row is computed twice vertically.  Wave w of a group accumulates,
+// A workgroup of eight waves (one per CU, 101 KB LDS) walks a strip of kHrWideStrip = 124 output columns
+// downwards, one row per step: waves 0-3 (group 0) own its left 60 columns, waves 4-7 (group 1) the
+// right 64, with rolling windows of the two intermediate activations in LDS rings, so neither
+// intermediate touches HBM and no row is computed twice vertically.  Each group computes 64 columns of
+// every layer.  On its own a group keeps 60 of them (each 3x3 layer costs a column on either side); here
+// group 1's windows begin inside group 0's columns, so the activations left of its first pixel are the
+// ones group 0 stored half a step earlier and all 64 of its output columns are valid: 124 of 128
+// computed columns are kept instead of 120 (see the ring layout at kHrWideRowPix).  The layout of two
+// independent strips of kHrStrip = 60 columns per workgroup remains as the template's other
+// instantiation (diagnostic builds compare the two; outputs are the same bytes).  Wave w of a group accumulates,
 // per step, its 32-pixel half (w & 1) of one row of conv4 (w < 2) or conv5 (w >= 2) as four 16 x 16
 // accumulators with 36 v_mfma_f32_16x16x32_f16 (one K-step per filter tap: all 32 input channels),
 // and its 16-pixel quarter of conv6 with 3 more: every wave issues the same matrix work.
@@ -44,11 +50,12 @@
 // The loop is unrolled by four so every ring slot and conv6 group is a compile-time
 // constant; segments start at multiples of four rows.
 //
-// Column bookkeeping for a strip whose first output column is X0:
-//   conv6 pixel i   = column X0 + i      (60 of 64 kept), reads a6 index i..i+2
-//   a6 ring index i = column X0 - 1 + i = conv5 pixel i, which reads a5 index i..i+2
-//   a5 ring index i = column X0 - 2 + i = conv4 pixel i, which reads a4 index i..i+2
-//   a4 index i      = column X0 - 3 + i   (66 pixels of conv_up1's row, read from memory)
+// Column bookkeeping for a strip whose first output column is X0, group G (G = 0 throughout in the layout of
+// independent 60-column strips):
+//   conv6 pixel i     = column X0 + 60 G + i  (G = 0: 60 of 64 kept; G = 1: all 64), reads a6 position 60 G + i ..+2
+//   a6 position 62 G + i = column X0 - 1 + 62 G + i = conv5 pixel i, which reads a5 position 62 G + i ..+2
+//   a5 position 64 G + i = column X0 - 2 + 64 G + i = conv4 pixel i, which reads a4 index i..i+2 of its group
+//   a4 index i        = column X0 - 3 + 64 G + i   (66 pixels of conv_up1's row, read from memory)
 // Activations outside the true image are written as zeros: that is the zero
 // padding each of the reference's convolutions applies to its own input
 // (Content/SuperResolution.cpp:245-268 via ML::Util::CreateConvolutionLayer); the
@@ -71,10 +78,22 @@ constexpr int kHrStride = 96;                         // pixel stride of all thr
                                                       // 16x16x32 B-operand reads (lane = pixel l & 15, channels 8 * (l >> 4) ..) conflict free
 constexpr int kHrRow = kHrRowPix * kHrStride;         // 6336
 constexpr int kHrA5 = 0;                              // per group: two rings of four rows (conv4's and conv5's outputs)
-constexpr int kHrA6 = 4 * kHrRow;
 constexpr int kHrGroupSmem = 8 * kHrRow;              // 50688
 constexpr int kHrW6 = 2 * kHrGroupSmem;               // conv6 filter fragments of rho == 0: [tap j][lane][16 B]
 constexpr int kHrSmem = kHrW6 + 3 * 1024;             // 104448
+// Seam-sharing layout (WIDE): the two groups are the halves of ONE strip of kHrWideStrip output columns and share
+// their rings, one row of kHrWideRowPix pixel positions per ring slot:
+//   a5 positions 0..63 = group 0's conv4 pixels, 64..127 = group 1's: columns X0 - 2 .. X0 + 125, all valid
+//   a6 positions 0..61 = group 0's valid conv5 pixels, 62..125 = group 1's: columns X0 - 1 .. X0 + 124
+// Group 1's conv5 and conv6 windows start two positions left of its own first pixel, inside group 0's part (conv5
+// pixel i of group 1 reads a5 positions 62 + i .., conv6 pixel i reads a6 positions 60 + i ..), so all 64 of its
+// output columns are valid: 60 + 64 = 124 of 128 computed columns are kept.  Group 0's two invalid conv5 pixels
+// would land on group 1's first two: they are stored to the unused positions 126, 127 instead.
+constexpr int kHrWideStrip = 124;
+constexpr int kHrWideRowPix = 130;
+constexpr int kHrWideRow = kHrWideRowPix * kHrStride;  // 12480
+constexpr int kHrWideW6 = 8 * kHrWideRow;              // 99840
+constexpr int kHrWideSmem = kHrWideW6 + 3 * 1024;      // 102912
 
 struct HrParams
 {
@@ -118,11 +137,15 @@ __device__ __forceinline__ void phaseBarrier()
 // in the matrix phase; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave spends in the
 // load phase, waiting at its barrier, in the matrix phase and waiting at that barrier.  The shipping library
 // instantiates EXP = 0 only.
-template <int EXP>
+template <int EXP, bool WIDE>
 __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smemAll[];
     constexpr bool PIN = (EXP & 1) == 0;
+    constexpr int kRow = WIDE ? kHrWideRow : kHrRow;           // bytes of one ring slot
+    constexpr int kA6 = 4 * kRow;                              // the a6 ring follows the four slots of a5
+    constexpr int kW6 = WIDE ? kHrWideW6 : kHrW6;
+    constexpr int kStrip = WIDE ? kHrWideStrip : kHrStrip;     // output columns per work item
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,7 +154,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     const int w4 = wave & 3;                      // wave within the group
     const int p16 = lane & 15, q = lane >> 4;     // 16x16x32 fragment coordinates: pixel (or output) within 16, group of 8 channels
     const int L = w4 >> 1, ti = w4 & 1;
-    char* const smem = smemAll + G * kHrGroupSmem;
+    char* const smem = smemAll + (WIDE ? 0 : G * kHrGroupSmem);
+    // WIDE: first ring position of this group's conv4 pixels (= a5), of its conv5 pixels (= a6; also the a5 position
+    // its conv5 window starts at) and the a6 position its conv6 window starts at
+    const int pos4 = WIDE ? 64 * G : 0, pos5 = WIDE ? 62 * G : 0, pos6 = WIDE ? 60 * G : 0;
 
     unsigned long long clk0 = 0, ref0 = 0;
     if constexpr (SRX_DIAG != 0)
@@ -159,10 +185,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     }
 
     // never-written pad columns of the rings must hold finite values
-    for (int i = tid * 16; i < kHrW6; i += kHrThreads * 16) *reinterpret_cast<uint4*>(smemAll + i) = uint4{0, 0, 0, 0};
-    if (tid < 192) reinterpret_cast<uint4*>(smemAll + kHrW6)[tid] = reinterpret_cast<const uint4*>(p.wpk6)[tid];
+    for (int i = tid * 16; i < kW6; i += kHrThreads * 16) *reinterpret_cast<uint4*>(smemAll + i) = uint4{0, 0, 0, 0};
+    if (tid < 192) reinterpret_cast<uint4*>(smemAll + kW6)[tid] = reinterpret_cast<const uint4*>(p.wpk6)[tid];
     // conv6 filter fragment of (rho, tap j) for this lane: row (p16 - 4 rho) & 15 of the rho == 0 fragment
-    const auto w6Lane = [&](int rho) { return kHrW6 + ((((p16 - 4 * rho) & 15) + 16 * q) * 16); };
+    const auto w6Lane = [&](int rho) { return kW6 + ((((p16 - 4 * rho) & 15) + 16 * q) * 16); };
 
     // Ring slots.  Row r of an item lives in slot (r - t0) & 3, t0 = the item's first step.  With
     // the loop unrolled by four the phase PH = (t - t0) & 3 is a compile-time constant, and so is
@@ -170,26 +196,31 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
     // one rotation is folded into these tables, indexed by a compile-time (PH + offset) & 3.
     const int rot = L ? 1 : 0;                     // (-lag) & 3
     const int inRing = kHrA5;                       // conv5's input; conv4 takes its input straight from HBM / L2
-    const int outRing = L ? kHrA6 : kHrA5;
+    const int outRing = L ? kA6 : kHrA5;
     int inSlot[4], outSlot[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-        inSlot[k] = inRing + ((k + rot) & 3) * kHrRow;
-        outSlot[k] = outRing + ((k + rot) & 3) * kHrRow;
+        inSlot[k] = inRing + ((k + rot) & 3) * kRow;
+        outSlot[k] = outRing + ((k + rot) & 3) * kRow;
     }
     const int lag = L ? 3 : 0;
-    const int colOff = (L ? -1 : -2) + ti * 32 + p16;              // + 16 for the second pixel half
-    const int inLane = (ti * 32 + p16) * kHrStride + q * 16;
-    const int in6Lane = kHrA6 + (w4 * 16 + p16) * kHrStride + q * 16;
-    const int outLane = (ti * 32 + p16) * kHrStride + q * 16;
+    const int colOff = (L ? -1 + pos5 : -2 + pos4) + ti * 32 + p16;  // column of this lane's pixel less the item's X0; + 16 for the second pixel half
+    const int inLane = (pos5 + ti * 32 + p16) * kHrStride + q * 16;
+    const int in6Lane = kA6 + (pos6 + w4 * 16 + p16) * kHrStride + q * 16;
+    const int outLane = ((L ? pos5 : pos4) + ti * 32 + p16) * kHrStride + q * 16;
+    // distance from the store of the first 16-pixel half to that of the second.  WIDE: group 0's conv5 pixels 62
+    // and 63 are not valid and their positions belong to group 1: those two lanes store to positions 126, 127.
+    int half2Off = 16 * kHrStride;
+    if (WIDE && G == 0 && L == 1 && ti == 1 && p16 >= 14) half2Off += 64 * kHrStride;
+    asm volatile("" : "+v"(half2Off));
     // this lane's store address in each slot of the output ring, kept in registers (made opaque: the compiler
     // would otherwise keep the lane part and add the slot in every step, one more vector instruction)
     int outAddr[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-        outAddr[k] = G * kHrGroupSmem + outSlot[k] + outLane;
+        outAddr[k] = (WIDE ? 0 : G * kHrGroupSmem) + outSlot[k] + outLane;
         asm volatile("" : "+v"(outAddr[k]));
     }
     // conv4's activation fragments come straight from conv_up1's output in HBM / L2: fragment (tap j, pixel half)
@@ -210,25 +241,31 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         const int Y1 = min(p.height2, Y0 + p.segRows);
         return ((((Y1 - 1) & ~3) + 12 - Y0) >> 2) + 1;
     };
-    const int numPairs = (p.numItems + 1) >> 1;
+    // A workgroup takes two items of kHrStrip columns, one per group, or (WIDE) one item of kHrWideStrip columns.
+    const int numPairs = WIDE ? p.numItems : (p.numItems + 1) >> 1;
     for (TileWalk tw(numPairs); tw.valid(); tw.next())
     {
         // the pair's items; an odd item count leaves the last group 1 a copy of the last item that stores nothing
-        const int itemRaw = 2 * tw.cur + G;
+        const int itemRaw = WIDE ? tw.cur : 2 * tw.cur + G;
         const bool itemValid = itemRaw < p.numItems;
         const int item = itemValid ? itemRaw : p.numItems - 1;
-        const int iters = max(itersOf(min(2 * tw.cur, p.numItems - 1)), itersOf(min(2 * tw.cur + 1, p.numItems - 1)));
+        const int iters = WIDE ? itersOf(item)
+                               : max(itersOf(min(2 * tw.cur, p.numItems - 1)), itersOf(min(2 * tw.cur + 1, p.numItems - 1)));
         const int f = item / perFrame;
         const int rem = item - f * perFrame;
         const int seg = rem / p.strips;
-        const int X0 = (rem - seg * p.strips) * kHrStrip;
+        const int X0 = (rem - seg * p.strips) * kStrip;
         const int Y0 = seg * p.segRows;                       // a multiple of 4
         const int Y1 = min(p.height2, Y0 + p.segRows);
         const int t0 = Y0 - 2;
 
         const long rowBytes = long(p.a4.pitch) * 64;
         // the a4 row to fetch next (uniform): one buffer descriptor per row covering the strip's 66 pixels
-        const char* rowPtr = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + (long(X0) - 3) * 32) + (Y0 - 3) * rowBytes;
+        const int a4Col = X0 - 3 + pos4;                      // column of a4 index 0 of this group
+        const char* rowPtr = reinterpret_cast<const char*>(p.a4.base + f * p.a4.frame + long(a4Col) * 32) + (Y0 - 3) * rowBytes;
+        // bytes of a row from that column to the end of the row's memory (4 border columns precede column 0); a
+        // group of a wide item can begin beyond it, and the descriptor then makes its loads return zeros
+        const int a4RowBytes = max(0, min(kHrRowPix, p.a4.pitch - 4 - a4Col)) * 64;
 
         // output rows at or beyond Y1 fall outside this descriptor and are dropped
         const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -237,8 +274,8 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
             const_cast<uint8_t*>(p.input) + f * p.inputFrame, 0, int(p.inputFrame), 0x00020000);
 
         // conv6: lane (p16, q) finishes the pixel (row 4B + q, column col6) of a block of rows 4B .. 4B+3
-        const int col6 = X0 + w4 * 16 + p16;
-        const bool laneOwns = itemValid && w4 * 16 + p16 < kHrStrip && col6 < p.width2;
+        const int col6 = X0 + pos6 + w4 * 16 + p16;
+        const bool laneOwns = itemValid && ((WIDE && G == 1) || w4 * 16 + p16 < kHrStrip) && col6 < p.width2;
         const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * 4u;
         // the residual term: NN2x(input) at that pixel = input pixel (2B + (q >> 1), col6 >> 1)
         const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * 4u;
@@ -246,7 +283,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         const bool colInside0 = X0 + colOff >= 0 && X0 + colOff < p.width2;
         const bool colInside1 = X0 + colOff + 16 >= 0 && X0 + colOff + 16 < p.width2;
         // all 32 columns of this wave inside (wave-uniform): then only the rows can fall outside
-        const int colFirst = X0 + (L ? -1 : -2) + ti * 32;
+        const int colFirst = X0 + (L ? -1 + pos5 : -2 + pos4) + ti * 32;
         const bool colsAllInside = colFirst >= 0 && colFirst + 31 < p.width2;
 
         __syncthreads();
@@ -275,7 +312,10 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         };
         const auto loadA4Row = [&](auto set) {
             constexpr int S = decltype(set)::value;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rowPtr), 0, kHrRowPix * 64, 0x00020000);
+            // (the size is uniform, but with the scalar registers all in use the compiler keeps it in a vector
+            // register, and a descriptor built from one is applied lane by lane unless it is told otherwise)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rowPtr), 0,
+                                                                                __builtin_amdgcn_readfirstlane(a4RowBytes), 0x00020000);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -306,7 +346,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 
             // ---- LDS addresses of this step
             const char* in2 = smem + inSlot[(PH + 1) & 3] + inLane;        // the newest row (rc+1) of the input ring
-            const char* c6 = smem + ((PH + 3) & 3) * kHrRow + in6Lane;     // row t-5 of a6
+            const char* c6 = smem + ((PH + 3) & 3) * kRow + in6Lane;       // row t-5 of a6
             char* outDst = smemAll + outAddr[(PH + 3) & 3];               // row rc-1 of the output ring
 
             unsigned long long stamp = 0;
@@ -356,7 +396,7 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 for (int a = 0; a < 4; ++a) fin[a] = ((a >> 1) ? inside1 : inside0) ? fin[a] : f16x4{0, 0, 0, 0};
             }
             *reinterpret_cast<f16x8*>(outDst) = __builtin_shufflevector(fin[0], fin[1], 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<f16x8*>(outDst + 16 * kHrStride) = __builtin_shufflevector(fin[2], fin[3], 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<f16x8*>(outDst + (WIDE ? half2Off : 16 * kHrStride)) = __builtin_shufflevector(fin[2], fin[3], 0, 1, 2, 3, 4, 5, 6, 7);
             lap(1);
 
             // conv6: the output row t-7 was finished by the last matrix phase; its group is (PH + 3) & 3
@@ -467,14 +507,37 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 
 }  // namespace
 
+// The layout the library runs: one item of kHrWideStrip columns per workgroup (true) or two of kHrStrip (false).
+constexpr bool kHrWide = true;
+#if SRX_DIAG
+namespace {
+int hrDiagExp()
+{
+    static const int exp = diagEnvInt("SRX_EXP", 0);
+    return exp;
+}
+bool hrWide()
+{
+    static const bool wide = diagEnvInt("SRX_HR_WIDE", kHrWide ? 1 : 0) != 0;      // the other layout, for A/B measurements
+    return wide;
+}
+}  // namespace
+#else
+namespace {
+constexpr bool hrWide() { return kHrWide; }
+}  // namespace
+#endif
+
 StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
 {
     StripPlan pl;
     if (width2 <= 0 || height2 <= 0 || batch <= 0 || numCUs <= 0) return pl;
-    pl.strips = (width2 + kHrStrip - 1) / kHrStrip;
-    // Rows are cut into segments where that fills the CUs better (a workgroup takes two items, one per CU):
-    // every segment re-computes 16 warm-up rows, so segments are at least 32 rows tall, and they start at
-    // multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
+    const bool wide = hrWide();
+    const int strip = wide ? kHrWideStrip : kHrStrip;
+    pl.strips = (width2 + strip - 1) / strip;
+    // Rows are cut into segments where that fills the CUs better (a workgroup takes one wide item or two narrow
+    // ones, one workgroup per CU): every segment re-computes 16 warm-up rows, so segments are at least 32 rows tall,
+    // and they start at multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
     const int maxSegs = height2 / 32 > 1 ? (height2 / 32 < 64 ? height2 / 32 : 64) : 1;
     long bestCost = 0;
 #if SRX_DIAG
@@ -489,7 +552,7 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
         c.segs = (height2 + c.segRows - 1) / c.segRows;
         c.items = c.strips * c.segs * batch;
         c.steps = c.segRows + 16;
-        const int pairs = (c.items + 1) / 2;
+        const int pairs = wide ? c.items : (c.items + 1) / 2;
         const int slots = gridFor(pairs, numCUs, 1);
         c.rounds = (pairs + slots - 1) / slots;
         c.cost = 100L * c.rounds * c.steps;
@@ -502,25 +565,18 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     return pl;
 }
 
-#if SRX_DIAG
-namespace {
-int hrDiagExp()
-{
-    static const int exp = diagEnvInt("SRX_EXP", 0);
-    return exp;
-}
-}  // namespace
-#endif
-
 hipError_t PrepareHrFused()
 {
-    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0>), kHrSmem);
+    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
 #if SRX_DIAG
     (void)hrDiagExp();
-    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<1>), kHrSmem);
-    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<2>), kHrSmem);
-    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<3>), kHrSmem);
-    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<4>), kHrSmem);
+    (void)hrWide();
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, !kHrWide>), kHrWide ? kHrSmem : kHrWideSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<1, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<2, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<3, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<4, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<4, !kHrWide>), kHrWide ? kHrSmem : kHrWideSmem);
 #endif
     return e;
 }
@@ -551,25 +607,32 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     // one input and one output frame must be addressable with a 32-bit byte offset
     if (p.imageFrame >= (1L << 31) || p.inputFrame >= (1L << 31)) return hipErrorInvalidValue;
 
-    const dim3 grid(gridFor((p.numItems + 1) / 2, numCUs, 1)), block(kHrThreads);
+    const bool wide = hrWide();
+    const dim3 grid(gridFor(wide ? p.numItems : (p.numItems + 1) / 2, numCUs, 1)), block(kHrThreads);
     // The kernel was loaded and its shared-memory limit raised by PrepareFusedKernels (srx_create): a launch is
     // the launch and nothing else.
 #if SRX_DIAG
     const int exp = hrDiagExp();
     ClockProbe* const probe = clockProbeFor(PROBE_HR_FUSED, int(grid.x), l.mayAllocate, s);
     p.clock = probe ? probe->dev : nullptr;
-    switch (exp)
+    constexpr int kSmemDefault = kHrWide ? kHrWideSmem : kHrSmem, kSmemOther = kHrWide ? kHrSmem : kHrWideSmem;
+    if (wide != kHrWide)
     {
-    case 1: hipLaunchKernelGGL(HrFusedKernel<1>, grid, block, kHrSmem, s, p); break;
-    case 2: hipLaunchKernelGGL(HrFusedKernel<2>, grid, block, kHrSmem, s, p); break;
-    case 3: hipLaunchKernelGGL(HrFusedKernel<3>, grid, block, kHrSmem, s, p); break;
-    case 4: hipLaunchKernelGGL(HrFusedKernel<4>, grid, block, kHrSmem, s, p); break;
-    default: hipLaunchKernelGGL(HrFusedKernel<0>, grid, block, kHrSmem, s, p); break;
+        if (exp == 4) hipLaunchKernelGGL((HrFusedKernel<4, !kHrWide>), grid, block, kSmemOther, s, p);
+        else hipLaunchKernelGGL((HrFusedKernel<0, !kHrWide>), grid, block, kSmemOther, s, p);
+    }
+    else switch (exp)
+    {
+    case 1: hipLaunchKernelGGL((HrFusedKernel<1, kHrWide>), grid, block, kSmemDefault, s, p); break;
+    case 2: hipLaunchKernelGGL((HrFusedKernel<2, kHrWide>), grid, block, kSmemDefault, s, p); break;
+    case 3: hipLaunchKernelGGL((HrFusedKernel<3, kHrWide>), grid, block, kSmemDefault, s, p); break;
+    case 4: hipLaunchKernelGGL((HrFusedKernel<4, kHrWide>), grid, block, kSmemDefault, s, p); break;
+    default: hipLaunchKernelGGL((HrFusedKernel<0, kHrWide>), grid, block, kSmemDefault, s, p); break;
     }
     clockProbeReport(probe, "HrFusedKernel", int(grid.x), s, exp == 4 ? 1024 : 0);
 #else
     p.clock = nullptr;
-    hipLaunchKernelGGL(HrFusedKernel<0>, grid, block, kHrSmem, s, p);
+    hipLaunchKernelGGL((HrFusedKernel<0, kHrWide>), grid, block, kHrWide ? kHrWideSmem : kHrSmem, s, p);
 #endif
     return hipGetLastError();
 }
