@@ -2,6 +2,11 @@
 """A/B timing of several builds of libsrx.so in ONE process, rounds interleaved (development helper).
 
   python tools/ab_libs.py base=gpurun_ab/libsrx_base.so new=superresolution_amd/libsrx.so [--rounds 7 --reps 10]
+  python tools/ab_libs.py narrow=gpurun_ab/a.so,SRX_HR_WIDE=0 wide=gpurun_ab/b.so,SRX_HR_WIDE=1
+
+A build may be followed by KEY=VALUE pairs: they are put into the environment before that build is loaded and its
+context created, which is when a diagnostic library reads its switches (once).  Two variants of ONE diagnostic
+library need two copies of the file under different names.
 
 Per build and round: the duration of one launch of each stage and of a whole upscale of a pass of 1080p
 frames (HIP events on the launch stream).  Prints median and minimum per build, and checks that the builds
@@ -32,6 +37,10 @@ def main():
     builds = []
     for spec in a.libs:
         name, path = spec.split("=", 1)
+        path, *env = path.split(",")
+        for kv in env:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
         L = _capi.load_library(os.path.abspath(path))
         ctx = _capi.SuperResolutionContext(a.w, a.h, batch=a.batch, library=L)
         for f in range(a.batch):
