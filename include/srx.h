@@ -204,7 +204,7 @@ srx_status srx_packed_weights(const char* weights_path, int32_t layer, uint16_t*
 
 /* Host-only: the fragments of layer 0..6 as the two FUSED kernels keep them in
  * registers (they differ from srx_packed_weights where a fused kernel uses
- * another MFMA shape or order): conv1 as ten K-steps by filter row; conv_up1 in
+ * another MFMA shape or order): conv1 as in srx_packed_weights (seven K-steps of four taps); conv_up1 in
  * its row-shared form, [wave = 2 * output half + column phase][30 fragments][lane][8]
  * (fragments 0..17: filter rows 0, 2, 4 with the five filter columns folded into
  * three column taps per phase; 18..29: filter rows 1, 3); conv2, conv3, conv4 and conv5 as

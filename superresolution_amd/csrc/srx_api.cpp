@@ -145,7 +145,7 @@ struct srx_ctx
     uint16_t* wpk[srx::kNumConvLayers] = {};
     float* bias[srx::kNumConvLayers] = {};
     uint16_t* wpk6Rows16 = nullptr;          // conv6 as row-streaming 16x16x32 fragments (fused kernel)
-    uint16_t* wpk1Rows8 = nullptr;           // conv1 as 10 K-steps (fused kernel)
+    uint16_t* wpk1Fused = nullptr;           // conv1 as 7 K-steps of four taps (fused kernel)
     uint16_t* wpkK32[6] = {};                // conv2, conv3, conv_up1 (row-shared form), conv4, conv5 as 16x16x32 fragments (fused kernels), by layer
     float* biasLrFused = nullptr;            // conv_up1 | conv3 | conv2 | conv1 biases (fused kernel)
     std::vector<StageKind> stages;           // launch sequence of one upscale
@@ -239,11 +239,11 @@ srx_status uploadWeights(srx_ctx* c)
         c->wpkK32[l] = static_cast<uint16_t*>(d);
     }
     {
-        const std::vector<uint16_t> packed = PackConv1Rows8(c->folded.filter[0]);
+        const std::vector<uint16_t> packed = PackConv1(c->folded.filter[0]);
         void* d = nullptr;
         if (const srx_status s = allocZero(c, &d, packed.size() * 2)) return s;
         SRX_HIP(hipMemcpy(d, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
-        c->wpk1Rows8 = static_cast<uint16_t*>(d);
+        c->wpk1Fused = static_cast<uint16_t*>(d);
 
         std::vector<float> b;
         for (int l : {3, 2, 1, 0})
@@ -443,7 +443,7 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
         LrFusedLaunch ll;
         ll.image = frameOffset(c->input, first);
         ll.a4 = c->tensor[SRX_T_CONV_UP1];
-        ll.wpk1 = c->wpk1Rows8;
+        ll.wpk1 = c->wpk1Fused;
         ll.wpk2 = c->wpkK32[1];
         ll.wpk3 = c->wpkK32[2];
         ll.wpkUp1 = c->wpkK32[3];
@@ -753,7 +753,7 @@ srx_status srx_upscale_static(srx_ctx* c, const void* in, size_t inPitch, void* 
     srx::LrFusedLaunch ll;
     ll.image = src;
     ll.a4 = a4;
-    ll.wpk1 = c->wpk1Rows8;
+    ll.wpk1 = c->wpk1Fused;
     ll.wpk2 = c->wpkK32[1];
     ll.wpk3 = c->wpkK32[2];
     ll.wpkUp1 = c->wpkK32[3];
@@ -930,7 +930,7 @@ srx_status srx_fused_weights(const char* path, int32_t layer, uint16_t* out, siz
         return fail(SRX_ERR_WEIGHTS, std::string("loadWeights: ") + path);
     const uint32_t* sz = srx::kConvLayers[layer].sizes;
     const std::vector<uint16_t> packed =
-        layer == 0 ? srx::PackConv1Rows8(folded.filter[0])
+        layer == 0 ? srx::PackConv1(folded.filter[0])
         : layer == 3 ? srx::PackConvUp1RowSharedK32(folded.filter[3])
         : layer <= 5 ? srx::PackConv3x3K32(folded.filter[layer], int(sz[0]), int(sz[1]), true)
                      : srx::PackConv6Rotating(folded.filter[6]);

@@ -76,7 +76,7 @@ struct LrFusedLaunch
 {
     Image image;                     // RGBA8 input
     Tensor a4;                       // conv_up1 output
-    const uint16_t *wpk1 = nullptr;  // conv1 as 10 K-steps (PackConv1Rows8)
+    const uint16_t *wpk1 = nullptr;  // conv1 as 7 K-steps (PackConv1)
     const uint16_t *wpk2 = nullptr, *wpk3 = nullptr, *wpkUp1 = nullptr;   // PackConv3x3K32 / PackConvUp1RowSharedK32
     const float* bias = nullptr;     // conv_up1[32] | conv3[64] | conv2[64] | conv1[32], fp32
     int width = 0, height = 0;       // input size

@@ -11,8 +11,8 @@
 //     waves 0-3  conv_up1, 16 of the 32 outputs of one column phase   2 chains of 60 MFMAs per step
 //     waves 4-5  conv3, 32 of the 64 outputs     2 chains of 72
 //     wave  6    conv2, all 64 outputs           4 chains of 36
-//     wave  7    conv1 + the input row loader    3 chains of 10 (32x32x16)
-// Waves w and w+4 share a SIMD, so every SIMD has 4224 MFMA cycles of work per step (2880 on
+//     wave  7    conv1 + the input row loader    3 chains of 7 (32x32x16: the 25 taps x 4 channels, four taps per K-step)
+// Waves w and w+4 share a SIMD, so every SIMD has 4224 MFMA cycles of work per step (2592 on
 // the last pair).
 //
 // conv_up1 (a 5x5 filter on the nearest-neighbour-upsampled tensor) is evaluated on the low-resolution tensor in
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         const f16x8* src = role == 0 ? p.wpkU + wave * 30 * 64
                          : role == 1 ? p.wpk3 + (wave - 4) * 36 * 64
                          : role == 2 ? p.wpk2 : p.wpk1;
-        const int n = role == 3 ? 10 : (role == 0 ? 30 : 36);
+        const int n = role == 3 ? 7 : (role == 0 ? 30 : 36);
 #pragma unroll
         for (int s = 0; s < 36; ++s) wreg[s] = src[(s < n ? s : 0) * 64 + lane];
         // make the loads land here: a load still pending at the loop would put a vmcnt wait in front
@@ -682,23 +682,33 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 const int r1 = t;
                 if (r1 <= Y1 + 2)
                 {
+                    // K-step s of a lane half h: taps 4s + 2h and 4s + 2h + 1 of the 25 (row-major, PackConv1), 4
+                    // channels each.  Byte offsets of the two taps' pixels from the lane's pixel in ring row 0; the
+                    // ring row of filter row i is uniform, which of two rows a lane reads depends on h only.  Taps
+                    // 25 .. 27 carry zero weights and read the last tap's pixel again.
+                    int rowOff[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) rowOff[i] = kX0Off + ((r1 + i - 2) & 7) * kX0Row;
+                    int tapLo[7], tapHi[7];
+                    forEach<7>([&](auto ss) {
+                        constexpr int S = decltype(ss)::value;
+                        constexpr int t00 = 4 * S < 24 ? 4 * S : 24, t01 = 4 * S + 1 < 24 ? 4 * S + 1 : 24;
+                        constexpr int t10 = 4 * S + 2 < 24 ? 4 * S + 2 : 24, t11 = 4 * S + 3 < 24 ? 4 * S + 3 : 24;
+                        tapLo[S] = h ? rowOff[t10 / 5] + (t10 % 5) * 8 : rowOff[t00 / 5] + (t00 % 5) * 8;
+                        tapHi[S] = h ? rowOff[t11 / 5] + (t11 % 5) * 8 : rowOff[t01 / 5] + (t01 % 5) * 8;
+                    });
 #pragma unroll
                     for (int tile = 0; tile < 3; ++tile)
                     {
                         f32x16 acc = biasAcc(smem, kBiasC1, h);
+                        const char* base = smem + (tile * 32 + px) * 8;
 #pragma unroll
-                        for (int i = 0; i < 5; ++i)
+                        for (int s7 = 0; s7 < 7; ++s7)
                         {
-                            // K-step (i, u): taps j = 4u + 2h and 4u + 2h + 1 of filter row i, 4 channels each
-                            const char* base = smem + kX0Off + ((r1 + i - 2) & 7) * kX0Row + (tile * 32 + px + 2 * h) * 8;
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                            {
-                                const f16x4 lo = *reinterpret_cast<const f16x4*>(base + u * 32);
-                                const f16x4 hi = *reinterpret_cast<const f16x4*>(base + u * 32 + 8);
-                                const f16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[i * 2 + u], b, acc, 0, 0, 0);
-                            }
+                            const f16x4 lo = *reinterpret_cast<const f16x4*>(base + tapLo[s7]);
+                            const f16x4 hi = *reinterpret_cast<const f16x4*>(base + tapHi[s7]);
+                            const f16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s7], b, acc, 0, 0, 0);
                         }
                         const int n = tile * 32 + px;
                         const int col = X0 - 3 + n;

@@ -420,24 +420,6 @@ std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw)
     return out;
 }
 
-std::vector<uint16_t> PackConv1Rows8(const std::vector<uint16_t>& oihw)
-{
-    std::vector<uint16_t> out(size_t(10) * 64 * 8, 0);
-    for (int i = 0; i < 5; ++i)
-        for (int u = 0; u < 2; ++u)
-            for (int lane = 0; lane < 64; ++lane)
-            {
-                const int o = lane & 31, h = lane >> 5;
-                for (int jj = 0; jj < 8; ++jj)
-                {
-                    const int j = 4 * u + 2 * h + (jj >> 2), c = jj & 3;
-                    if (j < 5 && c < 3)
-                        out[((size_t(i) * 2 + u) * 64 + lane) * 8 + jj] = oihw[((size_t(o) * 3 + c) * 5 + i) * 5 + j];
-                }
-            }
-    return out;
-}
-
 // Low-resolution tap (0..2) that 5x5 tap i reads for output phase p:
 // floor((p + i - 2) / 2) + 1.
 static int PhaseTap(int p, int i) { return ((p + i + 2) >> 1) - 1; }

@@ -139,10 +139,6 @@ std::vector<uint16_t> PackConv6Rotating(const std::vector<uint16_t>& oihw);
 // conv1 (5x5 on RGB0 pixels of 4 halfs): 7 ksteps of 4 taps x 4 channels,
 // k = 4 * (tap - 4*kstep) + channel; taps 25..27 and channel 3 are zero.
 std::vector<uint16_t> PackConv1(const std::vector<uint16_t>& oihw /*[32,3,5,5]*/);
-// conv1 with one filter row per pair of K-steps: kstep = 2 * row + u covers taps j = 4u .. 4u + 3 of
-// that row (taps 5..7 are zero), lane (o, h) element jj = tap 4u + 2h + (jj >> 2), channel jj & 3.
-// Ten K-steps; lets a kernel address each filter row's pixels from one base.
-std::vector<uint16_t> PackConv1Rows8(const std::vector<uint16_t>& oihw /*[32,3,5,5]*/);
 // conv_up1 in four-phase form: the 5x5 filter on the 2x nearest-neighbour
 // upsampled tensor equals, for output phase (py,px), a 3x3 filter on the
 // low-resolution tensor whose taps are sums of the 5x5 taps that read the same

@@ -212,17 +212,20 @@ def test_fused_conv6_rotating_layout():
 
 
 def test_fused_conv1_layout():
+    """conv1 in the fused kernel: seven K-steps of four taps (row-major over the 5x5) x four channels; lane (o, h)
+    holds taps 4s + 2h and 4s + 2h + 1; taps 25 .. 27 and the fourth channel are zero.  The same fragments as the
+    layer-wise kernel's."""
     f, _ = S.fold_weights(0)
-    w = f.reshape(32, 3, 5, 5)
-    p = S.fused_weights(0).reshape(5, 2, 64, 8)
-    for i in range(5):
-        for u in range(2):
-            for lane in (0, 9, 31, 32, 50, 63):
-                o, h = lane & 31, lane >> 5
-                for jj in range(8):
-                    tap, c = 4 * u + 2 * h + (jj >> 2), jj & 3
-                    want = w[o, c, i, tap] if (tap < 5 and c < 3) else 0
-                    assert p[i, u, lane, jj] == want
+    w = f.reshape(32, 3, 25)
+    p = S.fused_weights(0).reshape(7, 64, 8)
+    assert np.array_equal(p.ravel(), S.packed_weights(0).ravel())
+    for s in range(7):
+        for lane in (0, 9, 31, 32, 50, 63):
+            o, h = lane & 31, lane >> 5
+            for jj in range(8):
+                tap, c = 4 * s + 2 * h + (jj >> 2), jj & 3
+                want = w[o, c, tap] if (tap < 25 and c < 3) else 0
+                assert p[s, lane, jj] == want
 
 
 def test_layer_factories_reproduce_the_reference_buffer_plan():
