@@ -336,9 +336,11 @@ def test_frame_pipe_matches_plain_upscale():
 
 
 @pytest.mark.parametrize("w,h,batch", [(1, 1, 1), (2, 3, 1), (29, 2, 1), (30, 31, 1), (31, 64, 1), (59, 5, 2), (60, 60, 1),
-                                       (61, 33, 1), (121, 7, 3), (7, 130, 1), (30, 301, 1), (95, 263, 1), (180, 90, 5)])
+                                       (61, 33, 1), (62, 9, 1), (63, 9, 2), (121, 7, 3), (124, 6, 1), (125, 5, 1), (7, 130, 1), (30, 301, 1),
+                                       (95, 263, 1), (180, 90, 5)])
 def test_fused_path_edge_sizes(rowshared_model, w, h, batch):
-    """The two fused kernels (the product path) at sizes around their strip width (60 columns), their
+    """The two fused kernels (the product path) at sizes around their strip widths (60 input columns; 124 output
+    columns = 62 input columns, of which the left 60 output columns belong to the first wave group), their
     row segments (long thin images are cut into several; segments of the 2x grid start at multiples of
     four rows) and their four-row output blocks: against the oracle, and frame by frame."""
     frames = [synthetic_rgba(w, h, 4000 + 7 * w + h + i) for i in range(batch)]
