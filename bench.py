@@ -163,7 +163,8 @@ def pcie_inclusive(S, frames, device):
     n = rounds * slots * per_slot
     return {"frames_per_s": round(n / dt, 1), "output_megapixels_per_s": round(n / dt * 4 * W * H / 1e6, 1),
             "note": f"{n} frames host->GPU->host through srx_pipe_* (pinned buffers, {slots} slots x {per_slot} frames, "
-                    "upload / compute / download on three streams, RGB8 buffers); 6.2 MB in + 24.9 MB out per frame over PCIe"}
+                    "upload / compute / download on three streams, RGB8 buffers read and written by the fused kernels themselves); "
+                    "6.2 MB in + 24.9 MB out per frame over PCIe"}
 
 
 def single_frame_latency(S, frame, device, reps=50):

@@ -263,8 +263,10 @@ srx_status srx_pipe_destroy(srx_pipe* pipe);
 uint32_t   srx_pipe_slots(const srx_pipe* pipe);
 /* Channels per pixel of the pinned buffers, 4 = RGBA8 (default) or 3 = RGB8: the
  * loader's expansion of 3-channel data (XUSG/Advanced/XUSGTextureLoader.h:20) and
- * SaveImage's dropped alpha (SuperResolutionX.cpp:423-443) then happen on the GPU
- * and a quarter less data crosses PCIe.  Before the first srx_pipe_submit. */
+ * SaveImage's dropped alpha (SuperResolutionX.cpp:423-443) then happen on the GPU,
+ * inside the two fused kernels (they read and write three bytes per pixel; there
+ * is no repacking pass), and a quarter less data crosses PCIe.  Before the first
+ * srx_pipe_submit. */
 srx_status srx_pipe_set_channels(srx_pipe* pipe, uint32_t in_channels, uint32_t out_channels);
 srx_status srx_pipe_input(srx_pipe* pipe, uint32_t slot, uint8_t** host_rgba,
                           size_t* pitch, size_t* frame_stride);

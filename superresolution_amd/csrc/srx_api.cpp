@@ -410,8 +410,11 @@ srx::Image frameOffset(const srx::Image& im, uint32_t frame)
     return r;
 }
 
-// Launch one stage for frames [first, first + count).
-srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t count, hipStream_t s)
+// Launch one stage for frames [first, first + count).  `in` / `out`, where given, stand for the ctx's own input /
+// output images of those frames (frame 0 of the override = frame `first`): the two fused kernels then read / write
+// them instead, RGBA8 or RGB8.
+srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t count, hipStream_t s,
+                       const srx::Image* in = nullptr, const srx::Image* out = nullptr)
 {
     using namespace srx;
     const int W = int(c->width), H = int(c->height);
@@ -425,13 +428,13 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
     {
         HrFusedLaunch hl;
         hl.a4 = c->tensor[SRX_T_CONV_UP1];
-        hl.input = frameOffset(c->input, first);
+        hl.input = in ? *in : frameOffset(c->input, first);
         hl.wpk4 = c->wpkK32[4];
         hl.wpk5 = c->wpkK32[5];
         hl.wpk6 = c->wpk6Rows16;
         hl.bias4 = c->bias[4];
         hl.bias5 = c->bias[5];
-        hl.image = frameOffset(c->output, first);
+        hl.image = out ? *out : frameOffset(c->output, first);
         hl.width2 = 2 * W;
         hl.height2 = 2 * H;
         hl.batch = int(count);
@@ -441,7 +444,7 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
     if (stage == ST_LR_FUSED)
     {
         LrFusedLaunch ll;
-        ll.image = frameOffset(c->input, first);
+        ll.image = in ? *in : frameOffset(c->input, first);
         ll.a4 = c->tensor[SRX_T_CONV_UP1];
         ll.wpk1 = c->wpk1Fused;
         ll.wpk2 = c->wpkK32[1];
@@ -698,7 +701,9 @@ srx_status srx_upscale(srx_ctx* c, void* stream) try
 }
 SRX_CATCH
 
-srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream) try
+// srx_upscale_frames on images other than the ctx's own: `in` / `out` (either may be NULL) hold frames
+// first .. first + count - 1 back to back from their frame 0, RGBA8 or RGB8.
+static srx_status upscaleFramesOn(srx_ctx* c, uint32_t first, uint32_t count, hipStream_t stream, const srx::Image* in, const srx::Image* out)
 {
     if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
         return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
@@ -708,10 +713,18 @@ srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* 
     for (uint32_t f = first; f < first + count; f += c->chunk)
     {
         const uint32_t n = std::min(c->chunk, first + count - f);
+        srx::Image inAt, outAt;
+        if (in) inAt = frameOffset(*in, f - first);
+        if (out) outAt = frameOffset(*out, f - first);
         for (size_t i = 0; i < c->stages.size(); ++i)
-            if (const srx_status s = launchStage(c, c->stages[i], f, n, static_cast<hipStream_t>(stream))) return s;
+            if (const srx_status s = launchStage(c, c->stages[i], f, n, stream, in ? &inAt : nullptr, out ? &outAt : nullptr)) return s;
     }
     return SRX_OK;
+}
+
+srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream) try
+{
+    return upscaleFramesOn(c, first, count, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 SRX_CATCH
 
@@ -1183,7 +1196,7 @@ srx_status srx_pipe_set_channels(srx_pipe* p, uint32_t inChannels, uint32_t outC
         return hipSuccess;
     };
     if (inChannels == 3 && p->devRgbIn.empty())
-        SRX_HIP(allocPerSlot(p->devRgbIn, size_t(c->width) * c->height * 3 * p->perSlot));
+        SRX_HIP(allocPerSlot(p->devRgbIn, size_t(c->width) * c->height * 3 * p->perSlot + 4));     // + 4: the last pixel is fetched as a 32-bit word
     if (outChannels == 3 && p->devRgbOut.empty())
         SRX_HIP(allocPerSlot(p->devRgbOut, size_t(c->width) * c->height * 12 * p->perSlot));
     p->inChannels = inChannels;
@@ -1230,15 +1243,26 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot) try
                                hipMemcpyHostToDevice, p->up));
     SRX_HIP(hipEventRecord(p->evUp[slot], p->up));
     SRX_HIP(hipStreamWaitEvent(p->comp, p->evUp[slot], 0));
-    // The channel repacking runs on the compute stream: the fused kernels are persistent and fill
-    // every CU, so a kernel on another stream would only get the GPU at an unpredictable kernel boundary.
+    // RGB8 buffers are read and written by the two fused kernels themselves (3 bytes per pixel, tightly packed
+    // frames): no repacking pass, which would cost two more trips through memory per frame on the compute stream.
+    srx::Image rgbIn, rgbOut;
     if (p->inChannels == 3)
-        SRX_HIP(srx::LaunchRgbToRgba(p->devRgbIn[slot], frameOffset(c->input, first), int(c->width), int(c->height),
-                                     int(p->perSlot), p->comp));
-    if (const srx_status s = srx_upscale_frames(c, first, p->perSlot, p->comp)) return s;
+    {
+        rgbIn.base = p->devRgbIn[slot];
+        rgbIn.pitch = int64_t(p->inPitch);
+        rgbIn.frame = int64_t(p->inFrame);
+        rgbIn.pixelBytes = 3;
+    }
     if (p->outChannels == 3)
-        SRX_HIP(srx::LaunchRgbaToRgb(frameOffset(c->output, first), p->devRgbOut[slot], int(c->width) * 2, int(c->height) * 2,
-                                     int(p->perSlot), p->comp));
+    {
+        rgbOut.base = p->devRgbOut[slot];
+        rgbOut.pitch = int64_t(p->outPitch);
+        rgbOut.frame = int64_t(p->outFrame);
+        rgbOut.pixelBytes = 3;
+    }
+    if (const srx_status s = upscaleFramesOn(c, first, p->perSlot, p->comp, p->inChannels == 3 ? &rgbIn : nullptr,
+                                             p->outChannels == 3 ? &rgbOut : nullptr))
+        return s;
     SRX_HIP(hipEventRecord(p->evComp[slot], p->comp));
     SRX_HIP(hipStreamWaitEvent(p->down, p->evComp[slot], 0));
     if (p->outChannels == 3)

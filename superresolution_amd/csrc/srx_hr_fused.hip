@@ -137,7 +137,10 @@ __device__ __forceinline__ void phaseBarrier()
 // in the matrix phase; 4 = with SRX_CLOCK, the first 16 workgroups also record the cycles each wave spends in the
 // load phase, waiting at its barrier, in the matrix phase and waiting at that barrier.  The shipping library
 // instantiates EXP = 0 only.
-template <int EXP, bool WIDE>
+// IN3 / OUT3: the input / output image holds 3 bytes per pixel (RGB8) instead of 4.  An input pixel is then fetched
+// as the unaligned 32-bit word that starts at its first byte (the descriptor covers one byte more than the frame for
+// the last pixel's word); an output pixel is stored as an unaligned 16-bit word and a byte.
+template <int EXP, bool WIDE, bool IN3 = false, bool OUT3 = false>
 __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smemAll[];
@@ -271,14 +274,14 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
         const __amdgpu_buffer_rsrc_t imageRsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.image + f * p.imageFrame, 0, int(long(Y1) * p.imagePitch), 0x00020000);
         const __amdgpu_buffer_rsrc_t inputRsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(p.input) + f * p.inputFrame, 0, int(p.inputFrame), 0x00020000);
+            const_cast<uint8_t*>(p.input) + f * p.inputFrame, 0, int(p.inputFrame) + (IN3 ? 1 : 0), 0x00020000);
 
         // conv6: lane (p16, q) finishes the pixel (row 4B + q, column col6) of a block of rows 4B .. 4B+3
         const int col6 = X0 + pos6 + w4 * 16 + p16;
         const bool laneOwns = itemValid && ((WIDE && G == 1) || w4 * 16 + p16 < kHrStrip) && col6 < p.width2;
-        const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * 4u;
+        const unsigned laneOut = unsigned(q) * unsigned(p.imagePitch) + unsigned(col6) * (OUT3 ? 3u : 4u);
         // the residual term: NN2x(input) at that pixel = input pixel (2B + (q >> 1), col6 >> 1)
-        const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * 4u;
+        const unsigned laneX0 = unsigned(q >> 1) * unsigned(p.inputPitch) + unsigned(min(col6, p.width2 - 1) >> 1) * (IN3 ? 3u : 4u);
         // conv4 / conv5: are this lane's two columns (one per 16-pixel half) inside the image?
         const bool colInside0 = X0 + colOff >= 0 && X0 + colOff < p.width2;
         const bool colInside1 = X0 + colOff + 16 >= 0 && X0 + colOff + 16 < p.width2;
@@ -427,8 +430,14 @@ __global__ __launch_bounds__(kHrThreads, 2) void HrFusedKernel(const HrParams p)
                 // offset beyond the descriptor's range, which the hardware drops
                 const int blk = t - 10;
                 const bool ok = laneOwns & (blk >= Y0);
-                const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xffffffffu;
-                __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
+                // (an offset that stays beyond the range with the 2 added for the third byte of an RGB8 pixel)
+                const unsigned off = ok ? laneOut + unsigned(blk) * unsigned(p.imagePitch) : 0xc0000000u;
+                if constexpr (OUT3)
+                {
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(c0 | (c1 << 8)), imageRsrc, int(off), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c2, imageRsrc, int(off + 2u), 0, 0);
+                }
+                else __builtin_amdgcn_raw_buffer_store_b32(c0 | (c1 << 8) | (c2 << 16) | 0xff000000u, imageRsrc, int(off), 0, 0);
                 hold0 = hold1 = hold2 = 0.0f;         // what the swaps above put into the accumulator
             }
             lap(2);
@@ -567,7 +576,11 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
 
 hipError_t PrepareHrFused()
 {
-    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide>), kHrWide ? kHrWideSmem : kHrSmem);
+    constexpr int kSmemShipped = kHrWide ? kHrWideSmem : kHrSmem;
+    hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide>), kSmemShipped);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide, true, false>), kSmemShipped);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide, false, true>), kSmemShipped);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(HrFusedKernel<0, kHrWide, true, true>), kSmemShipped);
 #if SRX_DIAG
     (void)hrDiagExp();
     (void)hrWide();
@@ -604,11 +617,21 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     p.segRows = plan.segRows;
     p.numItems = plan.items;
     if (p.numItems <= 0) return hipErrorInvalidValue;
+    for (const int b : {l.input.pixelBytes, l.image.pixelBytes})
+        if (b != 3 && b != 4) return hipErrorInvalidValue;
+    const bool in3 = l.input.pixelBytes == 3, out3 = l.image.pixelBytes == 3;
     // one input and one output frame must be addressable with a 32-bit byte offset
     if (p.imageFrame >= (1L << 31) || p.inputFrame >= (1L << 31)) return hipErrorInvalidValue;
 
     const bool wide = hrWide();
     const dim3 grid(gridFor(wide ? p.numItems : (p.numItems + 1) / 2, numCUs, 1)), block(kHrThreads);
+    // the shipped layout with RGB8 images on either side
+    const auto launchRgb = [&] {
+        constexpr int kSmem = kHrWide ? kHrWideSmem : kHrSmem;
+        if (in3 && out3) hipLaunchKernelGGL((HrFusedKernel<0, kHrWide, true, true>), grid, block, kSmem, s, p);
+        else if (in3) hipLaunchKernelGGL((HrFusedKernel<0, kHrWide, true, false>), grid, block, kSmem, s, p);
+        else hipLaunchKernelGGL((HrFusedKernel<0, kHrWide, false, true>), grid, block, kSmem, s, p);
+    };
     // The kernel was loaded and its shared-memory limit raised by PrepareFusedKernels (srx_create): a launch is
     // the launch and nothing else.
 #if SRX_DIAG
@@ -616,7 +639,12 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     ClockProbe* const probe = clockProbeFor(PROBE_HR_FUSED, int(grid.x), l.mayAllocate, s);
     p.clock = probe ? probe->dev : nullptr;
     constexpr int kSmemDefault = kHrWide ? kHrWideSmem : kHrSmem, kSmemOther = kHrWide ? kHrSmem : kHrWideSmem;
-    if (wide != kHrWide)
+    if (in3 || out3)
+    {
+        if (wide != kHrWide) return hipErrorInvalidValue;      // RGB8 images exist in the shipped layout only
+        launchRgb();
+    }
+    else if (wide != kHrWide)
     {
         if (exp == 4) hipLaunchKernelGGL((HrFusedKernel<4, !kHrWide>), grid, block, kSmemOther, s, p);
         else hipLaunchKernelGGL((HrFusedKernel<0, !kHrWide>), grid, block, kSmemOther, s, p);
@@ -632,7 +660,8 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s)
     clockProbeReport(probe, "HrFusedKernel", int(grid.x), s, exp == 4 ? 1024 : 0);
 #else
     p.clock = nullptr;
-    hipLaunchKernelGGL((HrFusedKernel<0, kHrWide>), grid, block, kHrWide ? kHrWideSmem : kHrSmem, s, p);
+    if (in3 || out3) launchRgb();
+    else hipLaunchKernelGGL((HrFusedKernel<0, kHrWide>), grid, block, kHrWide ? kHrWideSmem : kHrSmem, s, p);
 #endif
     return hipGetLastError();
 }

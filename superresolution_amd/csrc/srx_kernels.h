@@ -29,6 +29,8 @@ struct Image
     uint8_t* base = nullptr;
     int64_t pitch = 0;    // bytes per row
     int64_t frame = 0;    // bytes per frame
+    int pixelBytes = 4;   // 4 = RGBA8; 3 = RGB8 (the two fused kernels only; such an image must be followed by at
+                          // least one readable byte: its pixels are fetched as unaligned 32-bit words)
 };
 
 enum ConvKind
@@ -60,10 +62,10 @@ struct ConvLaunch
 struct HrFusedLaunch
 {
     Tensor a4;
-    Image input;                     // RGBA8 input image: the residual term is NN2x of its tensor value
+    Image input;                     // RGBA8 or RGB8 input image: the residual term is NN2x of its tensor value
     const uint16_t *wpk4 = nullptr, *wpk5 = nullptr, *wpk6 = nullptr;   // PackConv3x3K32, PackConv3x3K32, PackConv6Rotating
     const float *bias4 = nullptr, *bias5 = nullptr;
-    Image image;
+    Image image;                     // RGBA8 or RGB8 output
     int width2 = 0, height2 = 0;     // size of the 2x grid
     int batch = 1;
     bool mayAllocate = true;         // false: the launch must not allocate (no diagnostic probe buffer is created)
@@ -74,7 +76,7 @@ hipError_t LaunchHrFused(const HrFusedLaunch& l, int numCUs, hipStream_t s);
 // reads the RGBA8 input image, writes conv_up1's output on the 2x grid.
 struct LrFusedLaunch
 {
-    Image image;                     // RGBA8 input
+    Image image;                     // RGBA8 or RGB8 input
     Tensor a4;                       // conv_up1 output
     const uint16_t *wpk1 = nullptr;  // conv1 as 7 K-steps (PackConv1)
     const uint16_t *wpk2 = nullptr, *wpk3 = nullptr, *wpkUp1 = nullptr;   // PackConv3x3K32 / PackConvUp1RowSharedK32
@@ -104,10 +106,6 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
 // its place in a captured stream: inside a HIP graph a hipMemsetAsync of the workspace was seen to overlap the
 // kernel that follows it.
 hipError_t LaunchZero(void* p, size_t bytes, hipStream_t s);
-
-// Channel repacking for the frame pipe's RGB8 mode (tightly packed RGB frames <-> RGBA8 image frames).
-hipError_t LaunchRgbToRgba(const uint8_t* rgb, const Image& dst, int width, int height, int batch, hipStream_t s);
-hipError_t LaunchRgbaToRgb(const Image& src, uint8_t* rgb, int width, int height, int batch, hipStream_t s);
 
 hipError_t LaunchPack(const Image& src, const Tensor& dst, int width, int height, int batch, hipStream_t s);
 hipError_t LaunchUnpack(const Tensor& src, const Image& dst, int width, int height, int batch, hipStream_t s);

@@ -422,78 +422,6 @@ void clockProbeReport(ClockProbe* probePtr, const char* name, int blocks, hipStr
 }  // namespace dev
 
 namespace {
-
-// RGB8 (tightly packed, `pixels` per frame) -> frames of an RGBA8 image (alpha 255), as the loader
-// expands 3-channel files (XUSG/Advanced/XUSGTextureLoader.h:20).  Four pixels per thread.
-__global__ void RgbToRgbaKernel(const uint8_t* rgb, uint8_t* rgba, long pitch, long frame, int width, int height, int batch)
-{
-    const long perFrame = long(width) * height, groups = (perFrame + 3) / 4;
-    for (long i = long(blockIdx.x) * blockDim.x + threadIdx.x; i < groups * batch; i += long(gridDim.x) * blockDim.x)
-    {
-        const long f = i / groups, p0 = (i - f * groups) * 4;
-        const long y = p0 / width, x = p0 - y * width;
-        const uint8_t* s = rgb + (f * perFrame + p0) * 3;
-        if (x + 4 <= width && p0 + 4 <= perFrame && ((f * perFrame) & 3) == 0)
-        {
-            // 12 B in (4-byte aligned: p0 is a multiple of 4), 16 B out
-            const unsigned* w = reinterpret_cast<const unsigned*>(s);
-            const unsigned a = w[0], b = w[1], c = w[2];
-            uint4 o;
-            o.x = (a & 0xffffff) | 0xff000000u;
-            o.y = (a >> 24) | ((b & 0xffff) << 8) | 0xff000000u;
-            o.z = (b >> 16) | ((c & 0xff) << 16) | 0xff000000u;
-            o.w = (c >> 8) | 0xff000000u;
-            uint8_t* d = rgba + f * frame + y * pitch + x * 4;
-            if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) *reinterpret_cast<uint4*>(d) = o;
-            else
-            {
-                unsigned* dd = reinterpret_cast<unsigned*>(d);
-                dd[0] = o.x; dd[1] = o.y; dd[2] = o.z; dd[3] = o.w;
-            }
-        }
-        else
-            for (long p = p0; p < min(p0 + 4, perFrame); ++p)
-            {
-                const uint8_t* t = rgb + (f * perFrame + p) * 3;
-                const long yy = p / width, xx = p - yy * width;
-                *reinterpret_cast<unsigned*>(rgba + f * frame + yy * pitch + xx * 4) = t[0] | (t[1] << 8) | (t[2] << 16) | 0xff000000u;
-            }
-    }
-}
-
-// Frames of an RGBA8 image -> RGB8 (tightly packed): what SaveImage keeps (SuperResolutionX.cpp:423-443).
-__global__ void RgbaToRgbKernel(const uint8_t* rgba, long pitch, long frame, uint8_t* rgb, int width, int height, int batch)
-{
-    const long perFrame = long(width) * height, groups = (perFrame + 3) / 4;
-    for (long i = long(blockIdx.x) * blockDim.x + threadIdx.x; i < groups * batch; i += long(gridDim.x) * blockDim.x)
-    {
-        const long f = i / groups, p0 = (i - f * groups) * 4;
-        const long y = p0 / width, x = p0 - y * width;
-        uint8_t* d = rgb + (f * perFrame + p0) * 3;
-        if (x + 4 <= width && p0 + 4 <= perFrame && ((f * perFrame) & 3) == 0 &&
-            (reinterpret_cast<uintptr_t>(rgba + f * frame + y * pitch + x * 4) & 15) == 0)
-        {
-            // 16 B in, 12 B out (p0 is a multiple of 4, so both sides are 4-byte aligned)
-            const uint4 v = *reinterpret_cast<const uint4*>(rgba + f * frame + y * pitch + x * 4);
-            unsigned* o = reinterpret_cast<unsigned*>(d);
-            o[0] = (v.x & 0xffffff) | (v.y << 24);
-            o[1] = ((v.y >> 8) & 0xffff) | (v.z << 16);
-            o[2] = ((v.z >> 16) & 0xff) | (v.w << 8);
-        }
-        else
-            for (long p = p0; p < min(p0 + 4, perFrame); ++p)
-            {
-                const long yy = p / width, xx = p - yy * width;
-                const unsigned v = *reinterpret_cast<const unsigned*>(rgba + f * frame + yy * pitch + xx * 4);
-                uint8_t* o = rgb + (f * perFrame + p) * 3;
-                o[0] = uint8_t(v); o[1] = uint8_t(v >> 8); o[2] = uint8_t(v >> 16);
-            }
-    }
-}
-
-}  // namespace
-
-namespace {
 __global__ void ZeroKernel(uint4* p, size_t count)
 {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x)
@@ -514,22 +442,6 @@ hipError_t LaunchZero(void* p, size_t bytes, hipStream_t s)
     if (count == 0) return hipSuccess;
     const int blocks = int(std::min<size_t>((count + 255) / 256, 4096));
     hipLaunchKernelGGL(ZeroKernel, dim3(blocks), dim3(256), 0, s, static_cast<uint4*>(p), count);
-    return hipGetLastError();
-}
-
-hipError_t LaunchRgbToRgba(const uint8_t* rgb, const Image& dst, int width, int height, int batch, hipStream_t s)
-{
-    const long groups = (long(width) * height + 3) / 4 * batch;
-    const int blocks = int((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
-    hipLaunchKernelGGL(RgbToRgbaKernel, dim3(blocks), dim3(256), 0, s, rgb, dst.base, long(dst.pitch), long(dst.frame), width, height, batch);
-    return hipGetLastError();
-}
-
-hipError_t LaunchRgbaToRgb(const Image& src, uint8_t* rgb, int width, int height, int batch, hipStream_t s)
-{
-    const long groups = (long(width) * height + 3) / 4 * batch;
-    const int blocks = int((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
-    hipLaunchKernelGGL(RgbaToRgbKernel, dim3(blocks), dim3(256), 0, s, src.base, long(src.pitch), long(src.frame), rgb, width, height, batch);
     return hipGetLastError();
 }
 

@@ -271,7 +271,9 @@ __device__ __forceinline__ void upChain(f32x4 (&accS)[2], f32x4 (&accT)[2], cons
 // give: the conv3 and conv2 waves drop 20 MFMAs per step each (SIMDs 0-2: 4608 -> 4288 MFMA cycles) and the
 // conv1 wave issues 60 more on fragments it reads from the conv2 ring (SIMD 3: 3264 -> 4224), same total.
 // The shipping library instantiates EXP = 0 only.
-template <int EXP>
+// RGB3: the input image holds 3 bytes per pixel (RGB8) instead of 4; a pixel is then fetched as the unaligned 32-bit
+// word that starts at its first byte (the fourth byte, the next pixel's red, is ignored like alpha is).
+template <int EXP, bool RGB3 = false>
 __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,7 +359,9 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
         const auto fetch = [&](int row, int e) -> unsigned {
             const int col = X0 - 5 + e;
             const bool inside = row >= 0 && row < p.height && col >= 0 && col < p.width && e < 70;
-            return inside ? *reinterpret_cast<const unsigned*>(img + long(row) * p.imagePitch + col * 4) : 0u;
+            typedef unsigned __attribute__((aligned(1))) UnalignedWord;
+            if constexpr (RGB3) return inside ? *reinterpret_cast<const UnalignedWord*>(img + long(row) * p.imagePitch + col * 3) : 0u;
+            else return inside ? *reinterpret_cast<const unsigned*>(img + long(row) * p.imagePitch + col * 4) : 0u;
         };
         // CSImageToTensor: UNORM8 -> u/255 -> fp16.  u * (1/255) rounds to the same fp16 as u / 255
         // for all 256 inputs.
@@ -815,6 +819,7 @@ const LrDiag& lrDiag()
 hipError_t PrepareFusedKernels()
 {
     hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0>), kLrSmem);
+    if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<0, true>), kLrSmem);
 #if SRX_DIAG
     (void)lrDiag();
     if (e == hipSuccess) e = ensureDynamicLds(reinterpret_cast<const void*>(LrFusedKernel<1>), kLrSmem);
@@ -844,7 +849,8 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     p.segs = plan.segs;
     p.segRows = plan.segRows;
     p.numItems = plan.items;
-    if (p.numItems <= 0) return hipErrorInvalidValue;
+    if (p.numItems <= 0 || (l.image.pixelBytes != 3 && l.image.pixelBytes != 4)) return hipErrorInvalidValue;
+    const bool rgb3 = l.image.pixelBytes == 3;
     // a row of a4 must be addressable with a 32-bit byte offset
     if (long(l.a4.pitch) * 64 >= (1L << 31)) return hipErrorInvalidValue;
 
@@ -861,13 +867,17 @@ hipError_t LaunchLrFused(const LrFusedLaunch& l, int numCUs, hipStream_t s)
     case 1: hipLaunchKernelGGL(LrFusedKernel<1>, grid, block, kLrSmem, s, p); break;
     case 4: hipLaunchKernelGGL(LrFusedKernel<4>, grid, block, kLrSmem, s, p); break;
     case 8: hipLaunchKernelGGL(LrFusedKernel<8>, grid, block, kLrSmem, s, p); break;
-    default: hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p); break;
+    default:
+        if (rgb3) hipLaunchKernelGGL((LrFusedKernel<0, true>), grid, block, kLrSmem, s, p);
+        else hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p);
+        break;
     }
     clockProbeReport(probe, "LrFusedKernel", int(grid.x), s, (exp & 4) ? 1024 : 0);
 #else
     p.prioMask = kLrPrioMask;
     p.clock = nullptr;
-    hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p);
+    if (rgb3) hipLaunchKernelGGL((LrFusedKernel<0, true>), grid, block, kLrSmem, s, p);
+    else hipLaunchKernelGGL(LrFusedKernel<0>, grid, block, kLrSmem, s, p);
 #endif
     return hipGetLastError();
 }

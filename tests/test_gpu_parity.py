@@ -376,27 +376,49 @@ def test_uhd_input_window_matches_standalone_run():
     assert np.array_equal(o2[2 * halo:2 * (halo + s), 2 * halo:2 * (halo + s)], out[2 * y0:2 * (y0 + s), 2 * x0:2 * (x0 + s)])
 
 
-@pytest.mark.parametrize("w,h", [(70, 45), (33, 21)])
-def test_frame_pipe_rgb8_buffers(w, h):
-    """RGB8 pinned buffers: the expansion to RGBA and the dropped alpha happen on the GPU."""
+@pytest.mark.parametrize("w,h,cin,cout", [(70, 45, 3, 3), (33, 21, 3, 3), (125, 9, 3, 3), (61, 70, 3, 4), (63, 5, 4, 3), (1, 1, 3, 3)])
+def test_frame_pipe_rgb8_buffers(w, h, cin, cout):
+    """RGB8 pinned buffers: the two fused kernels read and write three bytes per pixel themselves (a pixel is
+    fetched as the unaligned 32-bit word at its first byte, stored as a 16-bit word and a byte): same bytes as the
+    RGBA8 path at sizes with one strip, several strips and a seam between the wave groups, for RGB8 on either side."""
     frames = [synthetic_rgba(w, h, 3100 + i) for i in range(6)]
     with S.SuperResolutionContext(w, h) as one:
         expect = [one.run(f) for f in frames]
-    with S.SuperResolutionContext(w, h, batch=6) as ctx, S.FramePipe(ctx, 3, in_channels=3, out_channels=3) as pipe:
+    with S.SuperResolutionContext(w, h, batch=6) as ctx, S.FramePipe(ctx, 3, in_channels=cin, out_channels=cout) as pipe:
         for s in range(2):
             buf = pipe.input(s)
-            assert buf.shape == (3, h, w, 3)
+            assert buf.shape == (3, h, w, cin)
             for k in range(3):
-                buf[k] = frames[s * 3 + k][..., :3]
+                buf[k] = frames[s * 3 + k][..., :cin]
             pipe.submit(s)
         for s in range(2):
             out = pipe.wait(s)
-            assert out.shape == (3, 2 * h, 2 * w, 3)
+            assert out.shape == (3, 2 * h, 2 * w, cout)
             for k in range(3):
-                assert np.array_equal(out[k], expect[s * 3 + k][..., :3])
+                assert np.array_equal(out[k], expect[s * 3 + k][..., :cout])
         with pytest.raises(S.SrxError):
             from superresolution_amd._capi import _check
             _check(pipe._L.srx_pipe_set_channels(pipe._h, 4, 4))        # too late: slots were submitted
+
+
+@pytest.mark.gpu
+def test_frame_pipe_rgb8_full_hd():
+    """RGB8 buffers at the benchmark size: 1920 columns are 32 strips of the first kernel and 31 of the second; two
+    slots of two frames, every byte against the RGBA8 path."""
+    w, h = 1920, 1080
+    frames = [synthetic_rgba(w, h, 5200 + i) for i in range(4)]
+    with S.SuperResolutionContext(w, h) as one:
+        expect = [one.run(f)[..., :3].copy() for f in frames]
+    with S.SuperResolutionContext(w, h, batch=4) as ctx, S.FramePipe(ctx, 2, in_channels=3, out_channels=3) as pipe:
+        for s in range(2):
+            buf = pipe.input(s)
+            for k in range(2):
+                buf[k] = frames[s * 2 + k][..., :3]
+            pipe.submit(s)
+        for s in range(2):
+            out = pipe.wait(s)
+            for k in range(2):
+                assert np.array_equal(out[k], expect[s * 2 + k])
 
 
 @pytest.mark.gpu
