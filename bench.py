@@ -430,17 +430,22 @@ def main():
                                         ("" if args.config == "stream" else "; " + entry.get("_config", "")) + ")")
                 except Exception:
                     traffic, tj = None, {}
+            # what the matrix units actually run at: the MFMA work the dominant kernel issues per launch, padding
+            # included (the library reports it from its own plan), over the same launch time
+            issued = ctx.stage_issued_flops(ctx.stage_names().index(dom))
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP16_DENSE / 1e12,
                 "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_FP16_DENSE, 4), "traffic": traffic,
                 "achieved_direct_form": round(achieved_direct, 2),
                 "frac_direct_form": round(achieved_direct * 1e12 / PEAK_FP16_DENSE, 4),
                 "frac_four_phase_form": round(FLOP_PER_LR_PIXEL_PHASES[dom] * launch_pixels / dom_s / PEAK_FP16_DENSE, 4),
+                "issued": round(issued / dom_s / 1e12, 2), "frac_issued": round(issued / dom_s / PEAK_FP16_DENSE, 4),
                 "note": "achieved = FLOPs of the kernel's algorithm (conv_up1 in its row-shared form on the low-resolution "
                         "tensor, 3.33x fewer MACs than the reference's direct 5x5-on-upsampled form and 1.2x fewer than "
                         "four 3x3 phase filters: a cheaper form lowers this figure at equal speed) x input pixels per "
                         "launch / HIP-event launch time; *_direct_form counts conv_up1 as the "
-                        "reference evaluates it.  The chip holds about 1.8 GHz (not 2.4) under this MFMA "
+                        "reference evaluates it; issued = the MFMA work the kernel hands to the matrix units per launch, "
+                        "padded columns, taps and warm-up rows included (srx_stage_issued_flops).  The chip holds about 1.8 GHz (not 2.4) under this MFMA "
                         "load: a bare LDS-fed MFMA loop of the same shape measures 1.70 PFLOP/s here "
                         "(tools/mfma_shape_bench.hip).  " + traffic_note}
             info = ctx.device_info()

@@ -221,6 +221,12 @@ srx_status srx_fused_weights(const char* weights_path, int32_t layer, uint16_t* 
 int32_t     srx_num_stages(const srx_ctx* ctx);
 const char* srx_stage_name(const srx_ctx* ctx, int32_t i);
 srx_status  srx_launch_stage(srx_ctx* ctx, int32_t i, void* stream);
+/* Matrix-instruction FLOPs one launch of fused stage `i` issues for a pass of
+ * srx_frames_per_launch() frames, padding included (items x row steps x the
+ * MFMAs a workgroup issues per step): divided by the launch time it is the
+ * rate the matrix units actually run at, whatever share of it is useful.
+ * No counterpart in the reference (measurement only). */
+srx_status  srx_stage_issued_flops(const srx_ctx* ctx, int32_t i, double* flops);
 /* Frames one srx_launch_stage() of a convolution stage covers (the activation
  * workspace holds this many frames; srx_process walks the batch in such passes). */
 uint32_t    srx_frames_per_launch(const srx_ctx* ctx);

@@ -22,7 +22,7 @@ SYMBOLS = ["srx_create", "srx_destroy", "srx_get_out_size", "srx_get_in_size", "
            "srx_tensor_shape", "srx_fold_weights", "srx_packed_weights", "srx_num_stages", "srx_stage_name",
            "srx_launch_stage", "srx_frames_per_launch", "srx_device_info", "srx_last_error", "srx_upscale_frames",
            "srx_pipe_create", "srx_pipe_destroy", "srx_pipe_slots", "srx_pipe_input", "srx_pipe_submit",
-           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan",
+           "srx_pipe_wait", "srx_layer_conv2d", "srx_layer_upsample2d", "srx_layer_add", "srx_fused_weights", "srx_pipe_set_channels", "srx_layer_plan", "srx_stage_issued_flops",
            "srx_upscale_static", "srx_static_scratch_bytes"]
 
 
@@ -93,6 +93,7 @@ def load_library(path):
     L.srx_stage_name.argtypes = [vp, i32]
     L.srx_stage_name.restype = C.c_char_p
     L.srx_launch_stage.argtypes = [vp, i32, vp]
+    L.srx_stage_issued_flops.argtypes = [vp, i32, C.POINTER(C.c_double)]
     L.srx_last_error.restype = C.c_char_p
     L.srx_frames_per_launch.argtypes = [vp]
     L.srx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
@@ -232,6 +233,12 @@ class SuperResolutionContext:
 
     def launch_stage(self, i, stream=None):
         _check(self._L.srx_launch_stage(self._h, i, stream))
+
+    def stage_issued_flops(self, i):
+        """Matrix-instruction FLOPs one launch of fused stage i issues, padding included."""
+        v = C.c_double()
+        _check(self._L.srx_stage_issued_flops(self._h, i, C.byref(v)))
+        return v.value
 
     def run(self, rgba, frame=0):
         """Upload one RGBA8 frame, upscale, return the RGBA8 result (uint8 [2H,2W,4])."""

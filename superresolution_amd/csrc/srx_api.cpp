@@ -966,6 +966,26 @@ const char* srx_stage_name(const srx_ctx* c, int32_t i)
 
 uint32_t srx_frames_per_launch(const srx_ctx* c) { return validCtx(c) ? std::min(c->chunk, c->batch) : 0; }
 
+srx_status srx_stage_issued_flops(const srx_ctx* c, int32_t i, double* flops) try
+{
+    if (!validCtx(c) || i < 0 || i >= int32_t(c->stages.size()) || !flops) return fail(SRX_ERR_INVALID, "srx_stage_issued_flops: bad stage or pointer");
+    const StageKind st = c->stages[size_t(i)];
+    const int n = int(std::min(c->chunk, c->batch));
+    if (st == ST_LR_FUSED)
+    {
+        const srx::StripPlan pl = srx::PlanLrFused(int(c->width), int(c->height), n, c->numCUs);
+        *flops = double(pl.items) * pl.steps * srx::kLrIssuedFlopsPerStep;
+    }
+    else if (st == ST_HR_FUSED)
+    {
+        const srx::StripPlan pl = srx::PlanHrFused(2 * int(c->width), 2 * int(c->height), n, c->numCUs);
+        *flops = double(pl.items) * pl.steps * srx::kHrIssuedFlopsPerStep;
+    }
+    else return fail(SRX_ERR_STATE, "srx_stage_issued_flops: only the two fused kernels report their issued work");
+    return SRX_OK;
+}
+SRX_CATCH
+
 srx_status srx_device_info(const srx_ctx* c, int32_t* computeUnits, int32_t* clockKHz, char* arch, size_t archCap) try
 {
     if (!validCtx(c)) return fail(SRX_ERR_INVALID, "invalid ctx");

@@ -101,6 +101,12 @@ struct StripPlan
 };
 StripPlan PlanLrFused(int width, int height, int batch, int numCUs);
 StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs);
+// Matrix-instruction work one workgroup issues per row step of an item, padding included (FLOPs = 2 x multiply-adds
+// of the instruction shapes): LrFusedKernel 4 x 120 (conv_up1) + 2 x 144 (conv3) + 144 (conv2) v_mfma_f32_16x16x32_f16
+// and 21 v_mfma_f32_32x32x16_f16 (conv1); HrFusedKernel 8 waves x 39 v_mfma_f32_16x16x32_f16 (an item of the wide
+// layout; conv6's three per wave included).  items x steps x this = what a launch asks of the matrix units.
+constexpr double kLrIssuedFlopsPerStep = (4 * 120 + 2 * 144 + 144) * 16384.0 + 21 * 32768.0;
+constexpr double kHrIssuedFlopsPerStep = 8 * 39 * 16384.0;
 
 // Zero `bytes` bytes at `p` (both multiples of 16) with a plain kernel.  Unlike a memset node, a kernel node keeps
 // its place in a captured stream: inside a HIP graph a hipMemsetAsync of the workspace was seen to overlap the

@@ -520,6 +520,20 @@ def test_full_hd_runs_are_deterministic():
 
 
 @pytest.mark.gpu
+def test_issued_matrix_work_of_the_fused_stages():
+    """srx_stage_issued_flops: items x row steps x the MFMAs a workgroup issues per step.  A pass of eight 1080p frames is
+    256 strips of 60 columns walking 1080 + 12 rows in the first kernel and 248 strips of 124 columns walking
+    2160 + 16 rows in the second."""
+    with S.SuperResolutionContext(1920, 1080, batch=8) as ctx:
+        assert ctx.stage_names() == ["pack_conv1_conv2_conv3_conv_up1", "conv4_conv5_conv6_add_unorm"]
+        lr, hr = ctx.stage_issued_flops(0), ctx.stage_issued_flops(1)
+    assert lr == 256 * 1092 * ((4 * 120 + 2 * 144 + 144) * 16384 + 21 * 32768)
+    assert hr == 248 * 2176 * (8 * 39 * 16384)
+    # padding included, they exceed the algorithmic work of the same pass by 8 - 9 %
+    assert 1.05 < lr / (8 * 1920 * 1080 * 238272) < 1.12 and 1.05 < hr / (8 * 1920 * 1080 * 154368) < 1.10
+
+
+@pytest.mark.gpu
 def test_device_info():
     with S.SuperResolutionContext(16, 16) as ctx:
         info = ctx.device_info()
