@@ -545,9 +545,10 @@ StripPlan PlanHrFused(int width2, int height2, int batch, int numCUs)
     const int strip = wide ? kHrWideStrip : kHrStrip;
     pl.strips = (width2 + strip - 1) / strip;
     // Rows are cut into segments where that fills the CUs better (a workgroup takes one wide item or two narrow
-    // ones, one workgroup per CU): every segment re-computes 16 warm-up rows, so segments are at least 32 rows tall,
-    // and they start at multiples of four rows (conv6 stores blocks of four).  What counts is rounds x steps.
-    const int maxSegs = height2 / 32 > 1 ? (height2 / 32 < 64 ? height2 / 32 : 64) : 1;
+    // ones, one workgroup per CU): every segment re-computes 16 warm-up rows, so segments are at least 16 rows tall
+    // (small images then use many more CUs than they have strips), and they start at multiples of four rows (conv6
+    // stores blocks of four).  What counts is rounds x steps.
+    const int maxSegs = height2 / 8 > 1 ? (height2 / 8 < 128 ? height2 / 8 : 128) : 1;
     long bestCost = 0;
 #if SRX_DIAG
     static const int forced = diagEnvInt("SRX_SEGS_HR", 0);      // a fixed number of row segments, for measurements

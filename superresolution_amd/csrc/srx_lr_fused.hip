@@ -773,8 +773,10 @@ StripPlan PlanLrFused(int width, int height, int batch, int numCUs)
     if (width <= 0 || height <= 0 || batch <= 0 || numCUs <= 0) return pl;
     pl.strips = (width + kLrStrip - 1) / kLrStrip;
     // Rows are cut into segments where that fills the CUs better: every segment re-computes 12 warm-up
-    // rows, and what counts is rounds x steps (one workgroup per CU; segments at least 32 rows tall).
-    const int maxSegs = height / 32 > 1 ? (height / 32 < 64 ? height / 32 : 64) : 1;
+    // rows, and what counts is rounds x steps (one workgroup per CU).  Segments are at least 8 rows tall: a small
+    // image (the sample's own are 91 to 256 pixels a side) then spreads over many more CUs than its few strips, and
+    // its launch is 20 row steps long instead of 44; for large images the estimate never picks segments that short.
+    const int maxSegs = height / 4 > 1 ? (height / 4 < 128 ? height / 4 : 128) : 1;
     long bestCost = 0;
 #if SRX_DIAG
     static const int forced = diagEnvInt("SRX_SEGS_LR", 0);      // a fixed number of row segments, for measurements
