@@ -274,8 +274,8 @@ srx_status allocTensors(srx_ctx* c)
     // on its own by cutting its rows into segments, but every segment re-computes the pipeline's
     // warm-up rows; several frames per pass let the strips run the full height instead.  Among the
     // pass sizes the workspace limit allows (16 GB, SRX_WORKSPACE_MB overrides) take the one with
-    // the least estimated MFMA time per frame: the low-resolution kernel issues 3.2x the MFMA
-    // cycles per row step of the high-resolution one, whose two workgroups per CU run together.
+    // the least estimated time per frame: a row step of the low-resolution kernel takes 3.2x as
+    // long as one of the high-resolution kernel (2.8 against 0.88 us at 1080p).
     size_t limit = size_t(16) << 30;
     if (const char* env = std::getenv("SRX_WORKSPACE_MB"))
         limit = std::max<size_t>(1, std::strtoull(env, nullptr, 10)) << 20;
