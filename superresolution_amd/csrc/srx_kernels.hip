@@ -1,6 +1,6 @@
 // gfx950 (MI355X, CDNA4) kernels of the super-resolution path: the layer-wise kernels (one launch per
-// layer, every tensor in HBM; the per-layer parity path), the channel repacking of the frame pipe and
-// the in-kernel clock probe.  The product path runs on the two fused kernels in srx_lr_fused.hip and
+// layer, every tensor in HBM; the per-layer parity path), the workspace-clearing kernel and the in-kernel
+// clock probe of diagnostic builds.  The product path runs on the two fused kernels in srx_lr_fused.hip and
 // srx_hr_fused.hip.
 //
 // Every convolution here is an implicit GEMM on v_mfma_f32_32x32x16_f16 with
