@@ -123,14 +123,22 @@ __device__ __forceinline__ f16x4 reluHalf4(const f32x4& acc)
     return __builtin_elementwise_max(v, f16x4{0, 0, 0, 0});
 }
 
-// a + b as two packed fp32 additions (left to itself the compiler splits most of these into four scalar ones).
-__device__ __forceinline__ f32x4 addPacked(const f32x4& a, const f32x4& b)
+// ReLU(fp16(a + b)) of four values as two dwords: the addition and the conversion are ONE instruction per value
+// (v_fma_mix{lo,hi}_f16: a * 1.0 + b rounded once, to fp16; an fp32 addition followed by a conversion rounds twice and
+// differs from it by one fp16 unit in about one value of 25 000), which issues at the full vector rate: the same number
+// of instructions as two packed fp32 additions and two packed conversions, but a packed fp32 addition takes about four
+// times as long to issue beside the MFMAs.
+__device__ __forceinline__ uint2 addReluHalf4(const f32x4& a, const f32x4& b)
 {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 lo, hi;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    unsigned lo, hi;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2" : "=v"(lo) : "v"(a[0]), "v"(b[0]));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2" : "+v"(lo) : "v"(a[1]), "v"(b[1]));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2" : "=v"(hi) : "v"(a[2]), "v"(b[2]));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2" : "+v"(hi) : "v"(a[3]), "v"(b[3]));
+    const f16x2 z = {0, 0};
+    const f16x2 l = __builtin_elementwise_max(__builtin_bit_cast(f16x2, lo), z), h = __builtin_elementwise_max(__builtin_bit_cast(f16x2, hi), z);
+    return uint2{__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, h)};
 }
 
 // Initial accumulators of a 32-pixel x 32-output tile held as four 16 x 16 tiles (index = 2 * pixel
@@ -418,8 +426,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                     constexpr int part = P / 3 - 1, half = part >> 1, py = part & 1;
                     if constexpr (P % 3 == 0)
                     {
-                        const f16x4 v = reluHalf4(addPacked(accS[half], py ? accTn[half] : accTp[half]));
-                        const uint2 u = *reinterpret_cast<const uint2*>(&v);
+                        const uint2 u = addReluHalf4(accS[half], py ? accTn[half] : accTp[half]);
                         d[0] = u.x;
                         d[1] = u.y;
                     }
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
                 ring2 = ring2 + kA2Row == 5 * kA2Row ? 0 : ring2 + kA2Row;
                 stepBarrierReader();
             };
-            // The packed additions of `finish` are inline assembly, which the compiler's hazard recogniser does not look
+            // The additions of `finish` are inline assembly, which the compiler's hazard recogniser does not look
             // into: they must not read an accumulator before the MFMA that wrote it has retired.  Inside the loop they read
             // what the chain before the running one wrote (at least ten MFMAs earlier); after the loop the last tile is
             // finished right behind its last MFMA, hence the explicit wait states.
