@@ -489,6 +489,27 @@ srx_status launchStage(srx_ctx* c, StageKind stage, uint32_t first, uint32_t cou
 
 bool validCtx(const srx_ctx* c) { return c != nullptr && c->batch > 0; }
 
+// srx_upscale_frames on images other than the ctx's own: `in` / `out` (either may be NULL) hold frames
+// first .. first + count - 1 back to back from their frame 0, RGBA8 or RGB8.
+srx_status upscaleFramesOn(srx_ctx* c, uint32_t first, uint32_t count, hipStream_t stream, const srx::Image* in, const srx::Image* out)
+{
+    if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
+        return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
+    if (c->keep() || c->generic())
+        return fail(SRX_ERR_STATE, "srx_upscale_frames: not available with SRX_FLAG_KEEP_TENSORS or the generic-layer graph (their tensors are indexed by frame of the whole batch)");
+    SRX_HIP(hipSetDevice(c->device));
+    for (uint32_t f = first; f < first + count; f += c->chunk)
+    {
+        const uint32_t n = std::min(c->chunk, first + count - f);
+        srx::Image inAt, outAt;
+        if (in) inAt = frameOffset(*in, f - first);
+        if (out) outAt = frameOffset(*out, f - first);
+        for (size_t i = 0; i < c->stages.size(); ++i)
+            if (const srx_status s = launchStage(c, c->stages[i], f, n, stream, in ? &inAt : nullptr, out ? &outAt : nullptr)) return s;
+    }
+    return SRX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -700,27 +721,6 @@ srx_status srx_upscale(srx_ctx* c, void* stream) try
     return srx_process(c, stream);
 }
 SRX_CATCH
-
-// srx_upscale_frames on images other than the ctx's own: `in` / `out` (either may be NULL) hold frames
-// first .. first + count - 1 back to back from their frame 0, RGBA8 or RGB8.
-static srx_status upscaleFramesOn(srx_ctx* c, uint32_t first, uint32_t count, hipStream_t stream, const srx::Image* in, const srx::Image* out)
-{
-    if (!validCtx(c) || count == 0 || first >= c->batch || count > c->batch - first)
-        return fail(SRX_ERR_INVALID, "srx_upscale_frames: bad frame range");
-    if (c->keep() || c->generic())
-        return fail(SRX_ERR_STATE, "srx_upscale_frames: not available with SRX_FLAG_KEEP_TENSORS or the generic-layer graph (their tensors are indexed by frame of the whole batch)");
-    SRX_HIP(hipSetDevice(c->device));
-    for (uint32_t f = first; f < first + count; f += c->chunk)
-    {
-        const uint32_t n = std::min(c->chunk, first + count - f);
-        srx::Image inAt, outAt;
-        if (in) inAt = frameOffset(*in, f - first);
-        if (out) outAt = frameOffset(*out, f - first);
-        for (size_t i = 0; i < c->stages.size(); ++i)
-            if (const srx_status s = launchStage(c, c->stages[i], f, n, stream, in ? &inAt : nullptr, out ? &outAt : nullptr)) return s;
-    }
-    return SRX_OK;
-}
 
 srx_status srx_upscale_frames(srx_ctx* c, uint32_t first, uint32_t count, void* stream) try
 {
