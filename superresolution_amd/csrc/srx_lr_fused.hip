@@ -317,9 +317,10 @@ __global__ __launch_bounds__(kLrThreads, 2) void LrFusedKernel(const LrParams p)
     }
 
     // Waves w and w + 4 share a SIMD and its MFMA pipe.  The second-dispatched half (waves 4-7) loses
-    // the issue arbitration by age, hence a static priority for it.  With conv_up1 in the row-shared form the
-    // launch time is the same within 0.2 % for every assignment (none, conv_up1 only, all, this one): which wave
-    // of a SIMD runs ahead does not change how long the two take together.
+    // the issue arbitration by age, hence a static priority for it.  Measured on the final kernel, same run
+    // (bit r of the mask = role r at priority 1): conv3 + conv2 (+ conv1) above conv_up1, masks 6 and 14: 3.02 - 3.06 ms
+    // per launch; none (0), conv_up1 only (1), all (15), conv3 without conv2 (2, 10): 1.7 - 1.9 % slower; priority 3
+    // instead of 1: the same as 1.
     if ((p.prioMask >> role) & 1) __builtin_amdgcn_s_setprio(1);
 
     // pad columns of the rings are never written: they must hold finite values
