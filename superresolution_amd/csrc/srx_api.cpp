@@ -1253,9 +1253,11 @@ srx_status srx_pipe_submit(srx_pipe* p, uint32_t slot) try
         SRX_HIP(hipStreamWaitEvent(p->comp, p->evDown[slot], 0));
     }
     // Both sides of every copy are contiguous (tightly packed host frames; ctx images with pitch = width x 4 and
-    // frames back to back), so each slot moves as ONE linear copy per direction: linear copies between page-locked
-    // and device memory go to the DMA engines, which run beside the kernels; rectangular ones may be done by a
-    // copy kernel, which waits for CUs behind the persistent kernels of the compute stream.
+    // frames back to back), so each slot moves as ONE linear copy per direction: ROCm 7.2's runtime gives linear copies
+    // between page-locked and device memory to the DMA engines, which run beside the kernels (the runtime bundled
+    // with torch 2.10 does that for uploads only and downloads with a shader kernel, which shares the CUs with the
+    // persistent kernels: with three slots in flight it still hides, with more it does not); rectangular copies may
+    // be done by a copy kernel in either runtime.
     if (p->inChannels == 3)
         SRX_HIP(hipMemcpyAsync(p->devRgbIn[slot], p->hostIn[slot], p->inFrame * p->perSlot, hipMemcpyHostToDevice, p->up));
     else
